@@ -1,0 +1,185 @@
+/*
+ * vit_hash.h — C ABI of the MI355X batched Git-object hasher (libvit_hash.so).
+ *
+ * What it replaces.  The reference VCS computes every object id inline, one
+ * object at a time, with OpenSSL's one-shot SHA1() inside writeObject()
+ * (reference src/commit.cpp:88-95, declared src/commit.hpp:13; called per file
+ * from writeTree(), src/commit.cpp:139-173, and from writeBlob(), :116).  The
+ * reference has no plugin or FFI boundary at that point; this header IS the
+ * boundary a maintainer would cut there: the host keeps framing, tree assembly,
+ * deflate and storage, and hands batches of objects to the functions below,
+ * which return the same 20-byte ids SHA1() would have produced.
+ *
+ * Conventions.  Plain C types only.  Every function returns VIT_OK (0) or a
+ * negative VIT_ERR_* code and never throws or aborts; the text of the last
+ * error is kept per hasher (vit_last_error).  Digests are 20 raw bytes per
+ * object, in input order.  A vit_hasher may be used by one thread at a time.
+ * There is no CPU fallback: without a usable gfx950 device vit_hasher_create()
+ * fails with VIT_ERR_NODEVICE.
+ */
+#ifndef VIT_HASH_H
+#define VIT_HASH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIT_OK             0
+#define VIT_ERR_ARG       -1   /* null pointer, bad type string, size mismatch          */
+#define VIT_ERR_HIP       -2   /* a HIP runtime call failed (text in vit_last_error)    */
+#define VIT_ERR_NOMEM     -3   /* host or device allocation failed                      */
+#define VIT_ERR_RANGE     -4   /* arena too small / offset out of bounds / misaligned   */
+#define VIT_ERR_NODEVICE  -5   /* no gfx950 device visible                              */
+#define VIT_ERR_DEVICE_STATUS -6 /* a kernel flagged bad input (see vit_device_status)  */
+
+#define VIT_DIGEST_BYTES 20
+
+#define VIT_KERNEL_LDS   0     /* wave-cooperative loads staged through LDS (default)   */
+#define VIT_KERNEL_LANE  1     /* every lane loads its own blocks                       */
+
+typedef struct vit_hasher vit_hasher;
+
+/* ---- lifetime ------------------------------------------------------------ */
+
+/* Create a hasher over the given HIP device ordinals (n_devices == 0: every
+ * visible device; an ordinal may repeat, which gives two independent queues on
+ * one GPU).  Objects of a batch are sharded across the devices by bytes; no
+ * inter-GPU exchange takes place.  No counterpart in the reference (it has no
+ * device state); stands where the reference would link libcrypto
+ * (reference CMakeLists.txt:17-22). */
+int vit_hasher_create(const int *device_ids, int n_devices, vit_hasher **out);
+void vit_hasher_destroy(vit_hasher *h);
+
+/* Text of the last error on this hasher (h == NULL: last vit_hasher_create
+ * failure on the calling thread).  Reference convention: message on std::cerr
+ * and an empty result (src/commit.cpp:101-104). */
+const char *vit_last_error(const vit_hasher *h);
+
+int vit_hasher_device_count(const vit_hasher *h);
+
+/* Options: "kernel" (VIT_KERNEL_*), "host_threshold_bytes" (objects larger than
+ * this are hashed on host threads while the GPU batch runs, because one SHA-1
+ * stream is serial and a single lane is slower than a host core; 0 = never,
+ * the default is 16 MiB), "chunk_bytes" (pinned staging buffer size per queue),
+ * "pack_threads". */
+int vit_hasher_set_option(vit_hasher *h, const char *name, uint64_t value);
+
+/* Counters since creation: "objects_gpu", "objects_host", "blocks_gpu",
+ * "bytes_h2d", "launches", "last_kernel_ns", "last_pack_ns", "last_total_ns". */
+int vit_hasher_get_stat(const vit_hasher *h, const char *name, uint64_t *value);
+
+/* ---- framing (reference src/commit.cpp:90) ------------------------------- */
+
+/* Length of "<type> <len>\0": strlen(type) + 1 + decimal digits + 1. */
+uint32_t vit_header_len(const char *type, uint64_t len);
+/* Write that header into out (>= 32 bytes); returns its length. */
+uint32_t vit_write_header(const char *type, uint64_t len, uint8_t *out);
+/* 64-byte SHA-1 blocks of the framed, padded object: ceil((hdr + len + 9) / 64). */
+uint64_t vit_object_blocks(const char *type, uint64_t len);
+
+/* ---- batch hashing from host memory -------------------------------------- */
+
+/* ids of n objects of one type: digest i = SHA1("<type> <len[i]>\0" + data[i]).
+ * Replaces n calls of the SHA1() at reference src/commit.cpp:93-94.  The
+ * library packs the objects into pinned 64-byte-block arenas, copies them to
+ * the device(s) on HIP streams (packing of chunk k+1 overlaps copy and hashing
+ * of chunk k) and returns when all digests are written. */
+int vit_hash_objects(vit_hasher *h, const char *type, const uint8_t *const *data,
+                     const uint64_t *len, uint64_t n, uint8_t *digests);
+
+/* Same with type "blob": what writeBlob() hashes (reference src/commit.cpp:116). */
+int vit_hash_blobs(vit_hasher *h, const uint8_t *const *data, const uint64_t *len,
+                   uint64_t n, uint8_t *digests);
+
+/* id of ONE object computed on the calling host thread (SHA-NI when the CPU has
+ * it).  This is the routine the scheduler applies to objects above
+ * "host_threshold_bytes"; exported so that path can be checked on its own.
+ * Same result as the SHA1() at reference src/commit.cpp:93-94. */
+int vit_host_object_id(const char *type, const uint8_t *data, uint64_t len, uint8_t *digest);
+
+/* ---- pre-packed arenas ---------------------------------------------------- */
+
+/* Pinned host memory for arenas (hipHostMalloc); free with vit_arena_free. */
+int vit_arena_alloc(vit_hasher *h, uint64_t bytes, void **out);
+int vit_arena_free(vit_hasher *h, void *arena);
+
+/* Pack n objects back to back into `arena`: object i starts at offsets[i] (a
+ * multiple of 64) and occupies nblocks[i]*64 bytes holding header, content,
+ * 0x80, zero fill and the 64-bit big-endian bit length, i.e. exactly the bytes
+ * SHA-1 compresses.  *used_bytes = total.  VIT_ERR_RANGE if arena_bytes is too
+ * small (nothing written).  Host-only; needs no device.  Restates the framing
+ * of reference src/commit.cpp:90-91 plus FIPS 180-4 5.1.1 padding. */
+int vit_arena_pack(const char *type, const uint8_t *const *data, const uint64_t *len,
+                   uint64_t n, void *arena, uint64_t arena_bytes, uint64_t *offsets,
+                   uint32_t *nblocks, uint64_t *used_bytes, int threads);
+
+/* Length binning: order[] = object indices sorted by block count, longest
+ * first, ties in index order, so the 64 lanes of a wave finish together.
+ * Returns 1 if the order differs from identity, 0 if all counts are equal
+ * (order is then the identity and may be omitted), negative on error. */
+int vit_bin_order(const uint32_t *nblocks, uint64_t n, uint32_t *order);
+
+/* Hash a packed arena that lives in host memory on device queue `dev`
+ * (0 <= dev < vit_hasher_device_count).  Offsets and block counts are checked
+ * against arena_bytes on the host before anything is launched. */
+int vit_hash_arena(vit_hasher *h, int dev, const void *arena, uint64_t arena_bytes,
+                   const uint64_t *offsets, const uint32_t *nblocks, uint64_t n,
+                   uint8_t *digests);
+
+/* Hash a packed arena that is already resident in device memory; every pointer
+ * is a device pointer, d_order may be NULL, digests are written to device
+ * memory.  Asynchronous on `stream` (a hipStream_t; NULL = the queue's own
+ * stream).  Input that would read outside the arena is not hashed; the kernel
+ * raises a status bit instead (vit_device_status).  This is the launch the
+ * throughput benchmark times. */
+int vit_hash_arena_device(vit_hasher *h, int dev, const void *d_arena, uint64_t arena_bytes,
+                          const uint64_t *d_offsets, const uint32_t *d_nblocks,
+                          const uint32_t *d_order, uint64_t n, uint8_t *d_digests,
+                          void *stream);
+
+/* Wait for queue `dev`, then read and clear its status word (0 = clean;
+ * 1 out of bounds, 2 misaligned offset, 4 bad order entry). */
+int vit_device_status(vit_hasher *h, int dev, uint32_t *status);
+
+/* ---- device memory, for callers without a HIP binding of their own -------- */
+int vit_device_alloc(vit_hasher *h, int dev, uint64_t bytes, void **out);
+int vit_device_free(vit_hasher *h, int dev, void *p);
+int vit_device_upload(vit_hasher *h, int dev, void *d_dst, const void *src, uint64_t bytes);
+int vit_device_download(vit_hasher *h, int dev, void *dst, const void *d_src, uint64_t bytes);
+int vit_device_sync(vit_hasher *h, int dev);
+
+/* ---- synthetic inputs and measurement ------------------------------------ */
+
+/* Fill a device arena with n framed, padded objects whose content is the
+ * counter-based splitmix64 stream (seed, first_index + i).  d_lens == NULL:
+ * every object has len_each bytes, and d_offsets/d_nblocks are outputs;
+ * otherwise d_lens and d_offsets are inputs and d_nblocks is an output.
+ * The reference ships no benchmark inputs; this generator is this library's. */
+int vit_synth_arena_device(vit_hasher *h, int dev, const char *type, uint64_t seed,
+                           uint64_t first_index, uint64_t n, uint64_t len_each,
+                           const uint64_t *d_lens, uint64_t *d_offsets, uint32_t *d_nblocks,
+                           void *d_arena, uint64_t arena_bytes, void *stream);
+/* Host restatement of the same byte stream (for checking the generator). */
+void vit_synth_bytes(uint64_t seed, uint64_t index, uint8_t *dst, uint64_t len);
+
+/* Launch the device-resident hash `iters` times after `warmup` untimed
+ * launches and report each launch's duration in milliseconds, measured with
+ * HIP events on the launch stream. */
+int vit_time_hash_device(vit_hasher *h, int dev, const void *d_arena, uint64_t arena_bytes,
+                         const uint64_t *d_offsets, const uint32_t *d_nblocks,
+                         const uint32_t *d_order, uint64_t n, uint8_t *d_digests,
+                         int warmup, int iters, float *ms_each);
+
+/* Compute-only ceiling of the SHA-1 instruction stream on this device: n_lanes
+ * lanes each run blocks_per_lane compressions on register data.  *ms = one
+ * launch (best of iters). */
+int vit_valu_peak(vit_hasher *h, int dev, uint32_t n_lanes, uint32_t blocks_per_lane,
+                  int iters, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIT_HASH_H */

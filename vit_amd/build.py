@@ -1,0 +1,75 @@
+"""Build the native parts in-tree with hipcc (gfx950 only).
+
+    python -m vit_amd.build            # libvit_hash.so + the vit CLI
+    python -m vit_amd.build --force
+
+Outputs (git-ignored, shipped to the GPU box with the tree):
+    vit_amd/libvit_hash.so    C ABI of include/vit_hash.h (kernels + host pipeline)
+    vit_amd/bin/vit           hash-object / write-tree front end (C++ object store)
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libvit_hash.so")
+CLI = os.path.join(HERE, "bin", "vit")
+
+LIB_SOURCES = ["kernels.hip", "hasher.cpp", "packer.cpp", "sha1_host.cpp"]
+CLI_SOURCES = ["object_store.cpp", "vit_cli.cpp"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-I" + os.path.join(ROOT, "include")]
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found; the HIP library cannot be built")
+    return exe
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    deps = list(sources)
+    for d in (CSRC, os.path.join(ROOT, "include")):
+        deps += [os.path.join(d, f) for f in os.listdir(d) if f.endswith((".h", ".hpp"))]
+    return any(os.path.getmtime(s) > t for s in deps)
+
+
+def build_lib(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in LIB_SOURCES]
+    if not force and not _stale(LIB, srcs):
+        return LIB
+    cmd = [_hipcc()] + COMMON + ["--offload-arch=gfx950", "-shared", "-o", LIB] + srcs + ["-lpthread"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+def build_cli(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in CLI_SOURCES]
+    if not all(os.path.exists(s) for s in srcs):
+        return None
+    if not force and not _stale(CLI, srcs) and os.path.getmtime(CLI) >= os.path.getmtime(LIB):
+        return CLI
+    os.makedirs(os.path.dirname(CLI), exist_ok=True)
+    cmd = [_hipcc()] + COMMON + ["-o", CLI] + srcs + [
+        "-L" + HERE, "-lvit_hash", "-Wl,-rpath,$ORIGIN/..", "-lz", "-lpthread"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CLI
+
+
+def build_all(force=False, verbose=False):
+    build_lib(force, verbose)
+    build_cli(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,671 @@
+// hasher.cpp — the C ABI of include/vit_hash.h over the gfx950 kernels.
+//
+// Host pipeline of vit_hash_objects(), per device queue:
+//
+//   pack chunk k+1 into pinned arena B   |  H2D copy, kernel, digest D2H of
+//   (header, memcpy, padding; threads)   |  chunk k from pinned arena A (stream)
+//
+// Two staging sets per queue alternate, so host packing overlaps the copy
+// engine and the kernel.  Objects are assigned to queues by padded size (bytes),
+// not by count; nothing is exchanged between devices because every digest
+// depends on its own object only and the consumer of the digests (tree
+// assembly, reference src/commit.cpp:164-172) runs on the host.
+#include "../../include/vit_hash.h"
+#include "host_util.h"
+#include "kernels.h"
+#include "packer.h"
+#include "sha1_host.h"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+using clk = std::chrono::steady_clock;
+inline uint64_t ns_since(clk::time_point t0)
+{
+    return uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count());
+}
+
+thread_local std::string g_create_error;
+
+struct Staging {
+    uint8_t*  h_arena = nullptr;  uint64_t h_cap = 0;     // pinned host arena
+    uint8_t*  d_arena = nullptr;  uint64_t d_cap = 0;     // device arena
+    uint64_t* h_off = nullptr;    uint32_t* h_nb = nullptr;  uint32_t* h_order = nullptr;  uint8_t* h_dig = nullptr;
+    uint64_t* d_off = nullptr;    uint32_t* d_nb = nullptr;  uint32_t* d_order = nullptr;  uint8_t* d_dig = nullptr;
+    uint64_t  m_cap = 0;                                  // objects the meta buffers hold
+    hipEvent_t done = nullptr;
+    bool in_flight = false;
+    std::vector<uint64_t> obj;                            // caller indices of the chunk in flight
+};
+
+struct Queue {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t* d_status = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    Staging st[2];
+    std::string err;                                      // set by the queue's worker thread
+};
+
+}  // namespace
+
+struct vit_hasher {
+    std::vector<Queue> queues;
+    mutable std::string err;
+    int kernel = VIT_KERNEL_LDS;
+    uint64_t host_threshold = 16ull << 20;
+    uint64_t chunk_bytes = 256ull << 20;
+    int pack_threads = 8;
+    std::atomic<uint64_t> objects_gpu{0}, objects_host{0}, blocks_gpu{0}, bytes_h2d{0}, launches{0};
+    uint64_t last_kernel_ns = 0, last_pack_ns = 0, last_total_ns = 0;
+};
+
+namespace {
+
+int fail(const vit_hasher* h, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(h, expr)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail((h), e_ == hipErrorOutOfMemory ? VIT_ERR_NOMEM : VIT_ERR_HIP,         \
+                        "%s failed: %s", #expr, hipGetErrorString(e_));                       \
+    } while (0)
+
+// Same, inside a queue worker: record the text on the queue, return the code.
+#define HIP_TRYQ(q, expr)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            (q).err = std::string(#expr) + " failed: " + hipGetErrorString(e_);               \
+            return e_ == hipErrorOutOfMemory ? VIT_ERR_NOMEM : VIT_ERR_HIP;                   \
+        }                                                                                     \
+    } while (0)
+
+Queue* queue_of(vit_hasher* h, int dev)
+{
+    if (!h || dev < 0 || size_t(dev) >= h->queues.size()) return nullptr;
+    return &h->queues[size_t(dev)];
+}
+
+uint64_t round_up(uint64_t v, uint64_t q) { return (v + q - 1) / q * q; }
+
+int ensure_arena(Queue& q, Staging& s, uint64_t bytes)
+{
+    if (bytes <= s.h_cap && bytes <= s.d_cap) return VIT_OK;
+    const uint64_t cap = round_up(bytes < (1ull << 20) ? (1ull << 20) : bytes, 1ull << 20);
+    if (s.h_arena) { HIP_TRYQ(q, hipHostFree(s.h_arena)); s.h_arena = nullptr; s.h_cap = 0; }
+    if (s.d_arena) { HIP_TRYQ(q, hipFree(s.d_arena)); s.d_arena = nullptr; s.d_cap = 0; }
+    HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_arena), cap, hipHostMallocDefault));
+    s.h_cap = cap;
+    HIP_TRYQ(q, hipMalloc(reinterpret_cast<void**>(&s.d_arena), cap));
+    s.d_cap = cap;
+    return VIT_OK;
+}
+
+int ensure_meta(Queue& q, Staging& s, uint64_t n)
+{
+    if (n <= s.m_cap) return VIT_OK;
+    const uint64_t cap = round_up(n < 4096 ? 4096 : n, 4096);
+    if (s.h_off) {
+        HIP_TRYQ(q, hipHostFree(s.h_off));  HIP_TRYQ(q, hipHostFree(s.h_nb));
+        HIP_TRYQ(q, hipHostFree(s.h_order)); HIP_TRYQ(q, hipHostFree(s.h_dig));
+        HIP_TRYQ(q, hipFree(s.d_off)); HIP_TRYQ(q, hipFree(s.d_nb));
+        HIP_TRYQ(q, hipFree(s.d_order)); HIP_TRYQ(q, hipFree(s.d_dig));
+        s.h_off = nullptr; s.m_cap = 0;
+    }
+    HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_off), cap * 8, hipHostMallocDefault));
+    HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_nb), cap * 4, hipHostMallocDefault));
+    HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_order), cap * 4, hipHostMallocDefault));
+    HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_dig), cap * 20, hipHostMallocDefault));
+    HIP_TRYQ(q, hipMalloc(reinterpret_cast<void**>(&s.d_off), cap * 8));
+    HIP_TRYQ(q, hipMalloc(reinterpret_cast<void**>(&s.d_nb), cap * 4));
+    HIP_TRYQ(q, hipMalloc(reinterpret_cast<void**>(&s.d_order), cap * 4));
+    HIP_TRYQ(q, hipMalloc(reinterpret_cast<void**>(&s.d_dig), cap * 20));
+    s.m_cap = cap;
+    return VIT_OK;
+}
+
+void free_staging(Staging& s)
+{
+    if (s.h_arena) (void)hipHostFree(s.h_arena);
+    if (s.d_arena) (void)hipFree(s.d_arena);
+    if (s.h_off) {
+        (void)hipHostFree(s.h_off); (void)hipHostFree(s.h_nb); (void)hipHostFree(s.h_order); (void)hipHostFree(s.h_dig);
+        (void)hipFree(s.d_off); (void)hipFree(s.d_nb); (void)hipFree(s.d_order); (void)hipFree(s.d_dig);
+    }
+    if (s.done) (void)hipEventDestroy(s.done);
+    s = Staging();
+}
+
+vit::DeviceBatch make_batch(const Queue& q, const void* d_arena, uint64_t arena_bytes, const uint64_t* d_off,
+                            const uint32_t* d_nb, const uint32_t* d_order, uint64_t n, uint8_t* d_dig)
+{
+    vit::DeviceBatch b;
+    b.arena = static_cast<const uint8_t*>(d_arena);
+    b.arena_bytes = arena_bytes;
+    b.offsets = d_off; b.nblocks = d_nb; b.order = d_order;
+    b.n = uint32_t(n);
+    b.digests = d_dig;
+    b.status = q.d_status;
+    return b;
+}
+
+// Collect a finished chunk: wait for it and scatter its digests to the caller.
+int retire(Queue& q, Staging& s, uint8_t* digests)
+{
+    if (!s.in_flight) return VIT_OK;
+    HIP_TRYQ(q, hipEventSynchronize(s.done));
+    for (size_t i = 0; i < s.obj.size(); ++i) std::memcpy(digests + s.obj[i] * 20, s.h_dig + i * 20, 20);
+    s.in_flight = false;
+    return VIT_OK;
+}
+
+struct Job {
+    vit_hasher* h;
+    const char* type; uint32_t tl;
+    const uint8_t* const* data; const uint64_t* len;
+    const uint32_t* nb;                    // block count per object (all objects)
+    uint8_t* digests;
+};
+
+// Hash the objects `mine` (caller indices, in order) on queue q.
+int run_queue(Queue& q, const Job& job, const std::vector<uint64_t>& mine, uint64_t* pack_ns)
+{
+    vit_hasher* h = job.h;
+    HIP_TRYQ(q, hipSetDevice(q.device));
+    size_t pos = 0;
+    int turn = 0;
+    while (pos < mine.size()) {
+        // Chunk: as many objects as fit the staging budget (at least one).
+        uint64_t blocks = 0;
+        size_t end = pos;
+        while (end < mine.size()) {
+            const uint64_t nb = job.nb[mine[end]];
+            if (end > pos && (blocks + nb) * 64 > h->chunk_bytes) break;
+            blocks += nb; ++end;
+        }
+        const uint64_t cnt = end - pos, bytes = blocks * 64;
+        Staging& s = q.st[turn];
+        turn ^= 1;
+        int rc = retire(q, s, job.digests);
+        if (rc) return rc;
+        if ((rc = ensure_arena(q, s, bytes))) return rc;
+        if ((rc = ensure_meta(q, s, cnt))) return rc;
+
+        const auto t0 = clk::now();
+        s.obj.assign(mine.begin() + long(pos), mine.begin() + long(end));
+        std::vector<uint64_t> prefix(cnt + 1, 0);
+        for (uint64_t i = 0; i < cnt; ++i) {
+            s.h_off[i] = prefix[i] * 64;
+            s.h_nb[i] = job.nb[s.obj[i]];
+            prefix[i + 1] = prefix[i] + s.h_nb[i];
+        }
+        const int threads = bytes < (8u << 20) ? 1 : h->pack_threads;
+        vit::parallel_ranges(cnt, threads, prefix.data(), [&](int, uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i) {
+                const uint64_t o = s.obj[i];
+                vit::pack_one(job.type, job.tl, job.data[o], job.len[o], s.h_arena + s.h_off[i], s.h_nb[i]);
+            }
+        });
+        const bool binned = vit::bin_order(s.h_nb, cnt, s.h_order);
+        *pack_ns += ns_since(t0);
+
+        HIP_TRYQ(q, hipMemcpyAsync(s.d_arena, s.h_arena, bytes, hipMemcpyHostToDevice, q.stream));
+        HIP_TRYQ(q, hipMemcpyAsync(s.d_off, s.h_off, cnt * 8, hipMemcpyHostToDevice, q.stream));
+        HIP_TRYQ(q, hipMemcpyAsync(s.d_nb, s.h_nb, cnt * 4, hipMemcpyHostToDevice, q.stream));
+        if (binned) HIP_TRYQ(q, hipMemcpyAsync(s.d_order, s.h_order, cnt * 4, hipMemcpyHostToDevice, q.stream));
+        HIP_TRYQ(q, vit::launch_sha1(vit::KernelVariant(h->kernel),
+                                     make_batch(q, s.d_arena, bytes, s.d_off, s.d_nb, binned ? s.d_order : nullptr,
+                                                cnt, s.d_dig),
+                                     q.stream));
+        HIP_TRYQ(q, hipMemcpyAsync(s.h_dig, s.d_dig, cnt * 20, hipMemcpyDeviceToHost, q.stream));
+        HIP_TRYQ(q, hipEventRecord(s.done, q.stream));
+        s.in_flight = true;
+        h->objects_gpu += cnt; h->blocks_gpu += blocks; h->bytes_h2d += bytes + cnt * 16; ++h->launches;
+        pos = end;
+    }
+    for (Staging& s : q.st) {
+        int rc = retire(q, s, job.digests);
+        if (rc) return rc;
+    }
+    return VIT_OK;
+}
+
+// Split object indices over the queues by padded size: the few objects that
+// are large against a fair share go greedily to the least loaded queue, the
+// rest fill the queues in index order up to the fair share.
+void shard(const std::vector<uint64_t>& idx, const uint32_t* nb, size_t nq, std::vector<std::vector<uint64_t>>& out)
+{
+    out.assign(nq, {});
+    if (nq == 1) { out[0] = idx; return; }
+    uint64_t total = 0;
+    for (uint64_t i : idx) total += nb[i];
+    const uint64_t fair = total / nq + 1, big = fair / 4 + 1;
+    std::vector<uint64_t> load(nq, 0), large, small;
+    for (uint64_t i : idx) (nb[i] >= big ? large : small).push_back(i);
+    std::stable_sort(large.begin(), large.end(), [&](uint64_t a, uint64_t b) { return nb[a] > nb[b]; });
+    for (uint64_t i : large) {
+        size_t best = 0;
+        for (size_t k = 1; k < nq; ++k) if (load[k] < load[best]) best = k;
+        out[best].push_back(i); load[best] += nb[i];
+    }
+    size_t k = 0;
+    for (uint64_t i : small) {
+        while (k + 1 < nq && load[k] >= fair) ++k;
+        out[k].push_back(i); load[k] += nb[i];
+    }
+    for (auto& v : out) std::sort(v.begin(), v.end());
+}
+
+}  // namespace
+
+extern "C" {
+
+int vit_hasher_create(const int* device_ids, int n_devices, vit_hasher** out)
+{
+    if (!out || n_devices < 0 || (n_devices > 0 && !device_ids)) return fail(nullptr, VIT_ERR_ARG, "bad arguments");
+    *out = nullptr;
+    int visible = 0;
+    hipError_t e = hipGetDeviceCount(&visible);
+    if (e != hipSuccess || visible <= 0)
+        return fail(nullptr, VIT_ERR_NODEVICE, "no HIP device visible (%s); this library has no CPU path",
+                    e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+    std::vector<int> ids;
+    if (n_devices == 0) for (int d = 0; d < visible; ++d) ids.push_back(d);
+    else ids.assign(device_ids, device_ids + n_devices);
+
+    vit_hasher* h = new (std::nothrow) vit_hasher();
+    if (!h) return fail(nullptr, VIT_ERR_NOMEM, "out of host memory");
+    h->queues.resize(ids.size());
+    unsigned hw = std::thread::hardware_concurrency();
+    h->pack_threads = int(hw ? (hw > 16 ? 16 : hw) : 4);
+    for (size_t k = 0; k < ids.size(); ++k) {
+        Queue& q = h->queues[k];
+        q.device = ids[k];
+        hipDeviceProp_t prop;
+        hipError_t r = (ids[k] < 0 || ids[k] >= visible) ? hipErrorInvalidDevice : hipGetDeviceProperties(&prop, ids[k]);
+        if (r == hipSuccess && std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            fail(nullptr, VIT_ERR_NODEVICE, "device %d is %s; the kernels are built for gfx950 only", ids[k], prop.gcnArchName);
+            vit_hasher_destroy(h);
+            return VIT_ERR_NODEVICE;
+        }
+        if (r == hipSuccess) r = hipSetDevice(ids[k]);
+        if (r == hipSuccess) r = hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking);
+        if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void**>(&q.d_status), 256);
+        if (r == hipSuccess) r = hipMemset(q.d_status, 0, 256);
+        if (r == hipSuccess) r = hipEventCreate(&q.ev_a);
+        if (r == hipSuccess) r = hipEventCreate(&q.ev_b);
+        for (Staging& s : q.st)
+            if (r == hipSuccess) r = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
+        if (r != hipSuccess) {
+            fail(nullptr, VIT_ERR_HIP, "setting up device %d failed: %s", ids[k], hipGetErrorString(r));
+            vit_hasher_destroy(h);
+            return VIT_ERR_HIP;
+        }
+    }
+    *out = h;
+    return VIT_OK;
+}
+
+void vit_hasher_destroy(vit_hasher* h)
+{
+    if (!h) return;
+    for (Queue& q : h->queues) {
+        (void)hipSetDevice(q.device);
+        if (q.stream) (void)hipStreamSynchronize(q.stream);
+        for (Staging& s : q.st) free_staging(s);
+        if (q.d_status) (void)hipFree(q.d_status);
+        if (q.ev_a) (void)hipEventDestroy(q.ev_a);
+        if (q.ev_b) (void)hipEventDestroy(q.ev_b);
+        if (q.stream) (void)hipStreamDestroy(q.stream);
+    }
+    delete h;
+}
+
+const char* vit_last_error(const vit_hasher* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int vit_hasher_device_count(const vit_hasher* h) { return h ? int(h->queues.size()) : 0; }
+
+int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
+{
+    if (!h || !name) return VIT_ERR_ARG;
+    const std::string k(name);
+    if (k == "kernel") {
+        if (value != VIT_KERNEL_LDS && value != VIT_KERNEL_LANE) return fail(h, VIT_ERR_ARG, "unknown kernel %llu", (unsigned long long)value);
+        h->kernel = int(value);
+    } else if (k == "host_threshold_bytes") h->host_threshold = value;
+    else if (k == "chunk_bytes") h->chunk_bytes = value < (1u << 20) ? (1u << 20) : value;
+    else if (k == "pack_threads") h->pack_threads = value < 1 ? 1 : int(value > 256 ? 256 : value);
+    else return fail(h, VIT_ERR_ARG, "unknown option '%s'", name);
+    return VIT_OK;
+}
+
+int vit_hasher_get_stat(const vit_hasher* h, const char* name, uint64_t* value)
+{
+    if (!h || !name || !value) return VIT_ERR_ARG;
+    const std::string k(name);
+    if (k == "objects_gpu") *value = h->objects_gpu;
+    else if (k == "objects_host") *value = h->objects_host;
+    else if (k == "blocks_gpu") *value = h->blocks_gpu;
+    else if (k == "bytes_h2d") *value = h->bytes_h2d;
+    else if (k == "launches") *value = h->launches;
+    else if (k == "last_kernel_ns") *value = h->last_kernel_ns;
+    else if (k == "last_pack_ns") *value = h->last_pack_ns;
+    else if (k == "last_total_ns") *value = h->last_total_ns;
+    else if (k == "host_sha_accelerated") *value = vit::HostSha1::accelerated();
+    else return fail(h, VIT_ERR_ARG, "unknown stat '%s'", name);
+    return VIT_OK;
+}
+
+int vit_hash_objects(vit_hasher* h, const char* type, const uint8_t* const* data, const uint64_t* len,
+                     uint64_t n, uint8_t* digests)
+{
+    if (!h) return VIT_ERR_ARG;
+    const uint32_t tl = vit::type_len_checked(type);
+    if (!tl) return fail(h, VIT_ERR_ARG, "bad object type");
+    if (n == 0) return VIT_OK;
+    if (!data || !len || !digests) return fail(h, VIT_ERR_ARG, "null argument");
+    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 objects in one call");
+    const auto t0 = clk::now();
+
+    std::vector<uint32_t> nb(n);
+    std::vector<uint64_t> gpu_idx, host_idx;
+    gpu_idx.reserve(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (len[i] && !data[i]) return fail(h, VIT_ERR_ARG, "object %llu: null data with non-zero length", (unsigned long long)i);
+        const uint64_t b = (tl + 1 + vit::decimal_digits(len[i]) + 1 + len[i] + 9 + 63) / 64;
+        if (h->host_threshold && len[i] > h->host_threshold) { host_idx.push_back(i); nb[i] = 0; continue; }
+        if (b > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "object %llu too large for one lane", (unsigned long long)i);
+        nb[i] = uint32_t(b);
+        gpu_idx.push_back(i);
+    }
+
+    // Oversized objects: one SHA-1 stream each on host threads, beside the GPU batch.
+    std::vector<std::thread> host_workers;
+    std::atomic<size_t> next_host{0};
+    if (!host_idx.empty()) {
+        unsigned hw = std::thread::hardware_concurrency();
+        size_t nt = std::min<size_t>(host_idx.size(), hw ? hw : 4);
+        for (size_t t = 0; t < nt; ++t)
+            host_workers.emplace_back([&] {
+                for (size_t k; (k = next_host++) < host_idx.size();) {
+                    const uint64_t i = host_idx[k];
+                    vit::host_object_id(type, data[i], len[i], digests + i * 20);
+                }
+            });
+        h->objects_host += host_idx.size();
+    }
+
+    Job job{h, type, tl, data, len, nb.data(), digests};
+    std::vector<std::vector<uint64_t>> parts;
+    shard(gpu_idx, nb.data(), h->queues.size(), parts);
+    std::vector<int> rcs(h->queues.size(), VIT_OK);
+    std::vector<uint64_t> pack_ns(h->queues.size(), 0);
+    if (h->queues.size() == 1) {
+        rcs[0] = run_queue(h->queues[0], job, parts[0], &pack_ns[0]);
+    } else {
+        std::vector<std::thread> workers;
+        for (size_t k = 0; k < h->queues.size(); ++k)
+            workers.emplace_back([&, k] { rcs[k] = run_queue(h->queues[k], job, parts[k], &pack_ns[k]); });
+        for (auto& w : workers) w.join();
+    }
+    for (auto& w : host_workers) w.join();
+    h->last_pack_ns = 0;
+    for (uint64_t p : pack_ns) h->last_pack_ns = std::max(h->last_pack_ns, p);
+    h->last_total_ns = ns_since(t0);
+    for (size_t k = 0; k < rcs.size(); ++k)
+        if (rcs[k] != VIT_OK) return fail(h, rcs[k], "device queue %zu: %s", k, h->queues[k].err.c_str());
+    for (size_t k = 0; k < h->queues.size(); ++k) {
+        uint32_t st = 0;
+        int rc = vit_device_status(h, int(k), &st);
+        if (rc) return rc;
+        if (st) return fail(h, VIT_ERR_DEVICE_STATUS, "device queue %zu flagged status %u", k, st);
+    }
+    return VIT_OK;
+}
+
+int vit_hash_blobs(vit_hasher* h, const uint8_t* const* data, const uint64_t* len, uint64_t n, uint8_t* digests)
+{
+    return vit_hash_objects(h, "blob", data, len, n, digests);
+}
+
+int vit_host_object_id(const char* type, const uint8_t* data, uint64_t len, uint8_t* digest)
+{
+    if (!vit::type_len_checked(type) || !digest || (len && !data)) return VIT_ERR_ARG;
+    vit::host_object_id(type, data, len, digest);
+    return VIT_OK;
+}
+
+int vit_arena_alloc(vit_hasher* h, uint64_t bytes, void** out)
+{
+    if (!h || !out) return VIT_ERR_ARG;
+    *out = nullptr;
+    HIP_TRY(h, hipSetDevice(h->queues[0].device));
+    HIP_TRY(h, hipHostMalloc(out, bytes ? bytes : 64, hipHostMallocPortable));
+    return VIT_OK;
+}
+
+int vit_arena_free(vit_hasher* h, void* arena)
+{
+    if (!h) return VIT_ERR_ARG;
+    if (arena) HIP_TRY(h, hipHostFree(arena));
+    return VIT_OK;
+}
+
+int vit_hash_arena(vit_hasher* h, int dev, const void* arena, uint64_t arena_bytes, const uint64_t* offsets,
+                   const uint32_t* nblocks, uint64_t n, uint8_t* digests)
+{
+    Queue* q = queue_of(h, dev);
+    if (!q) return h ? fail(h, VIT_ERR_ARG, "no device queue %d", dev) : VIT_ERR_ARG;
+    if (n == 0) return VIT_OK;
+    if (!arena || !offsets || !nblocks || !digests) return fail(h, VIT_ERR_ARG, "null argument");
+    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 objects in one call");
+    uint64_t lo = ~0ull, hi = 0, blocks = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t sz = uint64_t(nblocks[i]) * 64;
+        if (offsets[i] & 15) return fail(h, VIT_ERR_RANGE, "object %llu: offset not 16-byte aligned", (unsigned long long)i);
+        if (offsets[i] > arena_bytes || sz > arena_bytes - offsets[i])
+            return fail(h, VIT_ERR_RANGE, "object %llu: %llu blocks at offset %llu exceed the arena (%llu bytes)",
+                        (unsigned long long)i, (unsigned long long)nblocks[i], (unsigned long long)offsets[i],
+                        (unsigned long long)arena_bytes);
+        lo = std::min(lo, offsets[i]); hi = std::max(hi, offsets[i] + sz); blocks += nblocks[i];
+    }
+    lo &= ~uint64_t(63);
+    const uint64_t span = hi > lo ? hi - lo : 0;
+    HIP_TRY(h, hipSetDevice(q->device));
+    Staging& s = q->st[0];
+    // Device-side staging only: the caller's arena is the host side.
+    if (span > s.d_cap) {
+        if (s.d_arena) { HIP_TRY(h, hipFree(s.d_arena)); s.d_arena = nullptr; s.d_cap = 0; }
+        if (s.h_arena) { HIP_TRY(h, hipHostFree(s.h_arena)); s.h_arena = nullptr; s.h_cap = 0; }
+        const uint64_t cap = round_up(span < (1ull << 20) ? (1ull << 20) : span, 1ull << 20);
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&s.d_arena), cap));
+        s.d_cap = cap;
+    }
+    if (int rc = ensure_meta(*q, s, n)) return fail(h, rc, "%s", q->err.c_str());
+    for (uint64_t i = 0; i < n; ++i) { s.h_off[i] = offsets[i] - lo; s.h_nb[i] = nblocks[i]; }
+    const bool binned = vit::bin_order(s.h_nb, n, s.h_order);
+    HIP_TRY(h, hipMemcpyAsync(s.d_arena, static_cast<const uint8_t*>(arena) + lo, span, hipMemcpyHostToDevice, q->stream));
+    HIP_TRY(h, hipMemcpyAsync(s.d_off, s.h_off, n * 8, hipMemcpyHostToDevice, q->stream));
+    HIP_TRY(h, hipMemcpyAsync(s.d_nb, s.h_nb, n * 4, hipMemcpyHostToDevice, q->stream));
+    if (binned) HIP_TRY(h, hipMemcpyAsync(s.d_order, s.h_order, n * 4, hipMemcpyHostToDevice, q->stream));
+    HIP_TRY(h, vit::launch_sha1(vit::KernelVariant(h->kernel),
+                                make_batch(*q, s.d_arena, span, s.d_off, s.d_nb, binned ? s.d_order : nullptr, n, s.d_dig),
+                                q->stream));
+    HIP_TRY(h, hipMemcpyAsync(s.h_dig, s.d_dig, n * 20, hipMemcpyDeviceToHost, q->stream));
+    HIP_TRY(h, hipStreamSynchronize(q->stream));
+    std::memcpy(digests, s.h_dig, n * 20);
+    h->objects_gpu += n; h->blocks_gpu += blocks; h->bytes_h2d += span + n * 16; ++h->launches;
+    uint32_t st = 0;
+    if (int rc = vit_device_status(h, dev, &st)) return rc;
+    if (st) return fail(h, VIT_ERR_DEVICE_STATUS, "device queue %d flagged status %u", dev, st);
+    return VIT_OK;
+}
+
+int vit_hash_arena_device(vit_hasher* h, int dev, const void* d_arena, uint64_t arena_bytes, const uint64_t* d_offsets,
+                          const uint32_t* d_nblocks, const uint32_t* d_order, uint64_t n, uint8_t* d_digests, void* stream)
+{
+    Queue* q = queue_of(h, dev);
+    if (!q) return h ? fail(h, VIT_ERR_ARG, "no device queue %d", dev) : VIT_ERR_ARG;
+    if (n == 0) return VIT_OK;
+    if (!d_arena || !d_offsets || !d_nblocks || !d_digests) return fail(h, VIT_ERR_ARG, "null argument");
+    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 objects in one call");
+    if (reinterpret_cast<uintptr_t>(d_arena) & 15) return fail(h, VIT_ERR_RANGE, "arena not 16-byte aligned");
+    HIP_TRY(h, hipSetDevice(q->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : q->stream;
+    HIP_TRY(h, vit::launch_sha1(vit::KernelVariant(h->kernel),
+                                make_batch(*q, d_arena, arena_bytes, d_offsets, d_nblocks, d_order, n, d_digests), s));
+    ++h->launches; h->objects_gpu += n;
+    return VIT_OK;
+}
+
+int vit_device_status(vit_hasher* h, int dev, uint32_t* status)
+{
+    Queue* q = queue_of(h, dev);
+    if (!q || !status) return h ? fail(h, VIT_ERR_ARG, "bad arguments") : VIT_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(q->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    HIP_TRY(h, hipMemcpy(status, q->d_status, 4, hipMemcpyDeviceToHost));
+    if (*status) HIP_TRY(h, hipMemset(q->d_status, 0, 4));
+    return VIT_OK;
+}
+
+int vit_device_alloc(vit_hasher* h, int dev, uint64_t bytes, void** out)
+{
+    Queue* q = queue_of(h, dev);
+    if (!q || !out) return h ? fail(h, VIT_ERR_ARG, "bad arguments") : VIT_ERR_ARG;
+    *out = nullptr;
+    HIP_TRY(h, hipSetDevice(q->device));
+    HIP_TRY(h, hipMalloc(out, bytes ? bytes : 256));
+    return VIT_OK;
+}
+
+int vit_device_free(vit_hasher* h, int dev, void* p)
+{
+    Queue* q = queue_of(h, dev);
+    if (!q) return h ? fail(h, VIT_ERR_ARG, "bad arguments") : VIT_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(q->device));
+    if (p) HIP_TRY(h, hipFree(p));
+    return VIT_OK;
+}
+
+int vit_device_upload(vit_hasher* h, int dev, void* d_dst, const void* src, uint64_t bytes)
+{
+    Queue* q = queue_of(h, dev);
+    if (!q || (bytes && (!d_dst || !src))) return h ? fail(h, VIT_ERR_ARG, "bad arguments") : VIT_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(q->device));
+    HIP_TRY(h, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return VIT_OK;
+}
+
+int vit_device_download(vit_hasher* h, int dev, void* dst, const void* d_src, uint64_t bytes)
+{
+    Queue* q = queue_of(h, dev);
+    if (!q || (bytes && (!dst || !d_src))) return h ? fail(h, VIT_ERR_ARG, "bad arguments") : VIT_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(q->device));
+    HIP_TRY(h, hipStreamSynchronize(q->stream));
+    HIP_TRY(h, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return VIT_OK;
+}
+
+int vit_device_sync(vit_hasher* h, int dev)
+{
+    Queue* q = queue_of(h, dev);
+    if (!q) return h ? fail(h, VIT_ERR_ARG, "bad arguments") : VIT_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(q->device));
+    HIP_TRY(h, hipDeviceSynchronize());
+    return VIT_OK;
+}
+
+int vit_synth_arena_device(vit_hasher* h, int dev, const char* type, uint64_t seed, uint64_t first_index, uint64_t n,
+                           uint64_t len_each, const uint64_t* d_lens, uint64_t* d_offsets, uint32_t* d_nblocks,
+                           void* d_arena, uint64_t arena_bytes, void* stream)
+{
+    Queue* q = queue_of(h, dev);
+    if (!q) return h ? fail(h, VIT_ERR_ARG, "no device queue %d", dev) : VIT_ERR_ARG;
+    const uint32_t tl = vit::type_len_checked(type);
+    if (!tl) return fail(h, VIT_ERR_ARG, "bad object type");
+    if (n == 0) return VIT_OK;
+    if (!d_offsets || !d_nblocks || !d_arena) return fail(h, VIT_ERR_ARG, "null argument");
+    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 objects in one call");
+    if (!d_lens) {
+        const uint64_t need = vit_object_blocks(type, len_each) * 64 * n;
+        if (need > arena_bytes) return fail(h, VIT_ERR_RANGE, "arena holds %llu bytes, %llu needed",
+                                            (unsigned long long)arena_bytes, (unsigned long long)need);
+    }
+    vit::SynthSpec s;
+    s.seed = seed; s.first_index = first_index; s.n = uint32_t(n); s.len_each = len_each;
+    s.lens = d_lens; s.offsets = d_offsets; s.nblocks = d_nblocks;
+    s.arena = static_cast<uint8_t*>(d_arena); s.arena_bytes = arena_bytes;
+    std::memset(s.type, 0, sizeof s.type);
+    std::memcpy(s.type, type, tl);
+    HIP_TRY(h, hipSetDevice(q->device));
+    HIP_TRY(h, vit::launch_synth(s, stream ? static_cast<hipStream_t>(stream) : q->stream));
+    return VIT_OK;
+}
+
+int vit_time_hash_device(vit_hasher* h, int dev, const void* d_arena, uint64_t arena_bytes, const uint64_t* d_offsets,
+                         const uint32_t* d_nblocks, const uint32_t* d_order, uint64_t n, uint8_t* d_digests,
+                         int warmup, int iters, float* ms_each)
+{
+    Queue* q = queue_of(h, dev);
+    if (!q || iters < 0 || warmup < 0 || (iters && !ms_each)) return h ? fail(h, VIT_ERR_ARG, "bad arguments") : VIT_ERR_ARG;
+    for (int i = 0; i < warmup; ++i)
+        if (int rc = vit_hash_arena_device(h, dev, d_arena, arena_bytes, d_offsets, d_nblocks, d_order, n, d_digests, nullptr)) return rc;
+    HIP_TRY(h, hipStreamSynchronize(q->stream));
+    for (int i = 0; i < iters; ++i) {
+        HIP_TRY(h, hipEventRecord(q->ev_a, q->stream));
+        if (int rc = vit_hash_arena_device(h, dev, d_arena, arena_bytes, d_offsets, d_nblocks, d_order, n, d_digests, nullptr)) return rc;
+        HIP_TRY(h, hipEventRecord(q->ev_b, q->stream));
+        HIP_TRY(h, hipEventSynchronize(q->ev_b));
+        HIP_TRY(h, hipEventElapsedTime(&ms_each[i], q->ev_a, q->ev_b));
+        h->last_kernel_ns = uint64_t(double(ms_each[i]) * 1e6);
+    }
+    return VIT_OK;
+}
+
+int vit_valu_peak(vit_hasher* h, int dev, uint32_t n_lanes, uint32_t blocks_per_lane, int iters, float* ms)
+{
+    Queue* q = queue_of(h, dev);
+    if (!q || !ms || iters < 1 || n_lanes == 0) return h ? fail(h, VIT_ERR_ARG, "bad arguments") : VIT_ERR_ARG;
+    HIP_TRY(h, hipSetDevice(q->device));
+    uint32_t* d_out = nullptr;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&d_out), uint64_t(n_lanes) * 4));
+    float best = 1e30f;
+    for (int i = 0; i < iters + 1; ++i) {            // first launch is a warm-up
+        hipError_t e = hipEventRecord(q->ev_a, q->stream);
+        if (e == hipSuccess) e = vit::launch_valu_peak(d_out, n_lanes, blocks_per_lane, q->stream);
+        if (e == hipSuccess) e = hipEventRecord(q->ev_b, q->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(q->ev_b);
+        float t = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, q->ev_a, q->ev_b);
+        if (e != hipSuccess) { (void)hipFree(d_out); return fail(h, VIT_ERR_HIP, "valu_peak: %s", hipGetErrorString(e)); }
+        if (i > 0 && t < best) best = t;
+    }
+    HIP_TRY(h, hipFree(d_out));
+    *ms = best;
+    return VIT_OK;
+}
+
+}  // extern "C"

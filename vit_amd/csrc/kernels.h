@@ -1,0 +1,62 @@
+// kernels.h — launch interface between the C-ABI host code and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vit {
+
+// Which SHA-1 kernel a launch uses.
+enum KernelVariant : int {
+    KERNEL_LDS  = 0,   // wave-cooperative coalesced loads staged through LDS (default)
+    KERNEL_LANE = 1,   // each lane loads its own blocks straight from global memory
+};
+
+// A packed arena in device memory.  Object i occupies nblocks[i] 64-byte blocks
+// starting at arena + offsets[i]; the bytes are the framed message
+// ("<type> <len>\0" + content) followed by SHA-1 padding (0x80, zeros, 64-bit
+// big-endian bit length), so the kernel hashes whole blocks and nothing else.
+struct DeviceBatch {
+    const uint8_t*  arena;        // device, 16-byte aligned
+    uint64_t        arena_bytes;  // bytes readable from arena
+    const uint64_t* offsets;      // device, n entries, each a multiple of 16 (the packer uses 64)
+    const uint32_t* nblocks;      // device, n entries
+    const uint32_t* order;        // device, n entries or nullptr: slot s hashes object order[s]
+    uint32_t        n;
+    uint8_t*        digests;      // device, n * 20 bytes, indexed by object
+    uint32_t*       status;       // device word, OR-ed with STATUS_* bits on bad input
+};
+
+enum : uint32_t {
+    STATUS_OUT_OF_BOUNDS = 1u,    // offsets[i] + 64*nblocks[i] > arena_bytes
+    STATUS_MISALIGNED    = 2u,    // offsets[i] not a multiple of 16
+    STATUS_BAD_ORDER     = 4u,    // order[s] >= n
+};
+
+hipError_t launch_sha1(KernelVariant v, const DeviceBatch& b, hipStream_t stream);
+
+// Synthetic framed arena, generated on the device (benchmark and full-size
+// parity inputs; the reference has no benchmark data of its own).
+// Content byte j of object i is byte j of the counter-based splitmix64 stream
+// keyed by (seed, first_index + i).  lens == nullptr: every object has len_each
+// bytes and offsets/nblocks are written by the kernel (slot = nblocks*64,
+// objects back to back); otherwise lens and offsets are inputs.
+struct SynthSpec {
+    uint64_t        seed;
+    uint64_t        first_index;
+    uint32_t        n;
+    uint64_t        len_each;
+    const uint64_t* lens;         // device or nullptr
+    uint64_t*       offsets;      // device: output if lens == nullptr, else input
+    uint32_t*       nblocks;      // device output
+    uint8_t*        arena;        // device output
+    uint64_t        arena_bytes;
+    char            type[8];      // "blob", "tree", "commit" (NUL padded)
+};
+hipError_t launch_synth(const SynthSpec& s, hipStream_t stream);
+
+// Compute-only ceiling: every lane runs `blocks_per_lane` SHA-1 compressions on
+// register-resident data (no loads in the loop).  out: one dword per lane.
+hipError_t launch_valu_peak(uint32_t* out, uint32_t n_lanes, uint32_t blocks_per_lane,
+                            hipStream_t stream);
+
+}  // namespace vit

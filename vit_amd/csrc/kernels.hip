@@ -1,0 +1,298 @@
+// kernels.hip — gfx950 kernels for batched Git-object SHA-1.
+//
+// Work decomposition: ONE LANE PER OBJECT.  SHA-1 is a serial chain over a
+// message's blocks, so the parallel unit is the object; a wave hashes 64 objects
+// in lock step, block by block.  The data-movement problem is that the 64
+// objects of a wave live at 64 unrelated arena addresses:
+//
+//  * sha1_lds_kernel (default) lets the wave fetch cooperatively: 4*BPS
+//    consecutive lanes read one object's next BPS blocks as one contiguous
+//    64*BPS-byte run (whole cache lines, 16 B per lane), written straight into
+//    LDS by global_load_lds_dwordx4.  Each lane then pulls its own object's
+//    blocks out of LDS with ds_read_b128.  The LDS image is XOR-swizzled on the
+//    global SOURCE address (the DMA destination is fixed at base + lane*16) so
+//    those reads are bank-conflict free.
+//  * sha1_lane_kernel is the plain form (each lane loads its own 64 bytes with
+//    four global_load_dwordx4, one block prefetched ahead); kept as the
+//    first-principles comparison and for A/B measurement.
+//
+// Both hash whole pre-padded blocks (see DeviceBatch) and write 20-byte digests.
+#include "kernels.h"
+#include "sha1_device.h"
+
+namespace vit {
+
+typedef __attribute__((address_space(1))) const void* global_cptr;
+typedef __attribute__((address_space(3))) void*       lds_ptr;
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t other = (uint32_t)__shfl_xor((int)v, o, 64);
+        v = other > v ? other : v;
+    }
+    return v;
+}
+
+// Resolve slot -> (object index, offset, block count) with the input checks
+// that keep a bad batch from faulting: anything out of range hashes 0 blocks
+// and raises a status bit instead.  `owns` says the slot has a digest to store.
+struct Slot { uint32_t idx; uint32_t nb; uint64_t off; bool owns; };
+
+__device__ __forceinline__ Slot resolve_slot(const DeviceBatch& b, uint32_t slot)
+{
+    const bool in_range = slot < b.n;
+    uint32_t idx = slot;
+    if (in_range && b.order) idx = b.order[slot];
+    const bool idx_ok = in_range && idx < b.n;
+    uint64_t off = 0;
+    uint32_t nb = 0;
+    if (idx_ok) { off = b.offsets[idx]; nb = b.nblocks[idx]; }
+    uint32_t bad = 0;
+    if (in_range && !idx_ok) bad |= STATUS_BAD_ORDER;
+    if (off & 15u) bad |= STATUS_MISALIGNED;
+    if (off > b.arena_bytes || (uint64_t)nb * 64u > b.arena_bytes - off) bad |= STATUS_OUT_OF_BOUNDS;
+    if (bad) { atomicOr(b.status, bad); nb = 0; }
+    Slot s;
+    s.idx = idx_ok ? idx : 0u; s.nb = nb; s.off = off; s.owns = idx_ok;
+    return s;
+}
+
+// ---------------------------------------------------------------- LDS-staged --
+// One wave per workgroup; no barrier is needed anywhere because a wave only ever
+// touches its own LDS.
+//
+// Stage t moves blocks [BPS*t, BPS*t + BPS) of all 64 objects.  Instruction j of
+// a stage (j < LPO) serves the OPI = 64/LPO objects j*OPI .. j*OPI+OPI-1, LPO =
+// 4*BPS lanes each: lane l serves object j*OPI + l/LPO and lands at LDS byte
+// j*1024 + l*16, i.e. row (l/LPO) of ROWB = 64*BPS bytes, 16-byte position
+// p = l % LPO.  Position p holds chunk c = p ^ sw(object) of the row, so the
+// lane fetches global chunk c.  Reader lane i wants chunk k of object i and
+// finds it at position k ^ sw(i).  sw(i) = (i / (16/LPO)) % LPO makes the 16
+// lanes of every ds_read_b128 lane group hit 16 different 16-byte bank slots.
+template <int BPS>
+__global__ __launch_bounds__(64) void sha1_lds_kernel(DeviceBatch b)
+{
+    constexpr int LPO  = 4 * BPS;        // lanes per object per instruction == instructions per stage
+    constexpr int OPI  = 64 / LPO;       // objects per instruction
+    constexpr int ROWB = 64 * BPS;       // bytes per object per stage
+    constexpr int RP   = 16 / LPO > 0 ? 16 / LPO : 1;   // rows per 256-byte bank line
+
+    __shared__ __attribute__((aligned(16))) uint8_t stage[64 * ROWB];
+
+    const uint32_t lane = threadIdx.x;
+    const uint32_t slot = blockIdx.x * 64u + lane;
+
+    const Slot me = resolve_slot(b, slot);
+    const uint32_t idx = me.idx, my_nb = me.nb;
+    const uint64_t my_off = me.off;
+    const bool owns = me.owns;
+
+    // Publish (offset, nblocks) of the wave's 64 objects; the tables borrow the
+    // stage buffer, which is not in use yet.
+    uint64_t* t_off = reinterpret_cast<uint64_t*>(stage);
+    uint32_t* t_nb  = reinterpret_cast<uint32_t*>(stage + 64 * 8);
+    t_off[lane] = my_off;
+    t_nb[lane]  = my_nb;
+    __syncthreads();
+
+    const uint8_t* src[LPO];     // this lane's source pointer for instruction j, stage 0
+    int32_t        lim[LPO];     // instruction j is live for this lane while BPS*t < lim[j]
+    const uint32_t p = lane % LPO;
+#pragma unroll
+    for (int j = 0; j < LPO; ++j) {
+        const uint32_t o  = j * OPI + lane / LPO;          // object (lane id) served
+        const uint32_t sw = (o / RP) % LPO;
+        const uint32_t c  = p ^ sw;                        // chunk of the row to fetch
+        src[j] = b.arena + t_off[o] + c * 16u;
+        lim[j] = (int32_t)t_nb[o] - (int32_t)(c >> 2);     // chunk c lies in block c/4 of the stage
+    }
+    const uint32_t my_sw  = (lane / RP) % LPO;
+    const uint32_t my_row = (lane / OPI) * 1024u + (lane % OPI) * ROWB;
+    const uint32_t max_nb = __builtin_amdgcn_readfirstlane(wave_max_u32(my_nb));
+    const uint32_t nst    = (max_nb + BPS - 1) / BPS;
+    __syncthreads();             // table reads are done before the first DMA lands on them
+
+    uint32_t h[5];
+    sha1_init(h);
+
+    auto issue = [&](uint32_t t) {
+#pragma unroll
+        for (int j = 0; j < LPO; ++j) {
+            if ((int32_t)(BPS * t) < lim[j])
+                __builtin_amdgcn_global_load_lds((global_cptr)(src[j] + (uint64_t)t * ROWB),
+                                                 (lds_ptr)(stage + j * 1024), 16, 0, 0);
+        }
+    };
+
+    if (nst) issue(0);
+    for (uint32_t t = 0; t < nst; ++t) {
+        // The DMA writes are tracked by vmcnt only; nothing else orders the
+        // ds_reads below behind them.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint4 q[LPO];
+#pragma unroll
+        for (int k = 0; k < LPO; ++k)
+            q[k] = *reinterpret_cast<const uint4*>(stage + my_row + ((k ^ my_sw) << 4));
+        // All of this stage is in registers before the next stage's DMA may
+        // overwrite the buffer.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t + 1 < nst) issue(t + 1);
+
+#pragma unroll
+        for (int s = 0; s < BPS; ++s) {
+            if (BPS * t + s < my_nb) {
+                uint32_t w[16];
+                put_words(w, 0, q[4 * s]);     put_words(w, 4, q[4 * s + 1]);
+                put_words(w, 8, q[4 * s + 2]); put_words(w, 12, q[4 * s + 3]);
+                sha1_compress(h, w);
+            }
+        }
+    }
+    if (owns) store_digest(b.digests, idx, h);
+}
+
+// ------------------------------------------------------------- lane-direct --
+__global__ __launch_bounds__(256) void sha1_lane_kernel(DeviceBatch b)
+{
+    const uint32_t slot = blockIdx.x * 256u + threadIdx.x;
+    const Slot me = resolve_slot(b, slot);
+    if (!me.owns) return;
+    const uint32_t idx = me.idx, nb = me.nb;
+    const uint64_t off = me.off;
+
+    uint32_t h[5];
+    sha1_init(h);
+    const uint4* p = reinterpret_cast<const uint4*>(b.arena + off);
+    uint4 q0, q1, q2, q3;
+    if (nb) { q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; }
+    for (uint32_t i = 0; i < nb; ++i) {
+        uint32_t w[16];
+        put_words(w, 0, q0); put_words(w, 4, q1); put_words(w, 8, q2); put_words(w, 12, q3);
+        if (i + 1 < nb) {
+            const uint4* nx = p + 4ull * (i + 1);
+            q0 = nx[0]; q1 = nx[1]; q2 = nx[2]; q3 = nx[3];
+        }
+        sha1_compress(h, w);
+    }
+    store_digest(b.digests, idx, h);
+}
+
+hipError_t launch_sha1(KernelVariant v, const DeviceBatch& b, hipStream_t stream)
+{
+    if (b.n == 0) return hipSuccess;
+    if (v == KERNEL_LANE) {
+        const uint32_t grid = (b.n + 255u) / 256u;
+        hipLaunchKernelGGL(sha1_lane_kernel, dim3(grid), dim3(256), 0, stream, b);
+    } else {
+        const uint32_t grid = (b.n + 63u) / 64u;
+        hipLaunchKernelGGL(sha1_lds_kernel<2>, dim3(grid), dim3(64), 0, stream, b);
+    }
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------- synthetic data --
+__device__ __forceinline__ uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint32_t ndigits_u64(uint64_t v)
+{
+    uint32_t d = 1;
+    while (v >= 10) { v /= 10; ++d; }
+    return d;
+}
+
+// One wave per object; lanes stride over the object's 16-byte chunks and
+// produce header, content, 0x80, zero fill and the bit length byte by byte.
+__global__ __launch_bounds__(256) void synth_arena_kernel(SynthSpec s)
+{
+    const uint32_t obj = blockIdx.x * 4u + threadIdx.x / 64u;
+    if (obj >= s.n) return;
+    const uint32_t lane = threadIdx.x & 63u;
+
+    const uint64_t len = s.lens ? s.lens[obj] : s.len_each;
+    uint32_t tl = 0;
+    while (tl < 8 && s.type[tl]) ++tl;
+    const uint32_t nd = ndigits_u64(len);
+    const uint64_t hl = tl + 1 + nd + 1;                 // "<type> <len>\0"
+    const uint64_t msg = hl + len;                       // framed message bytes
+    const uint64_t nb = (msg + 9 + 63) / 64;
+    uint64_t off;
+    if (s.lens) off = s.offsets[obj];
+    else { off = (uint64_t)obj * nb * 64u; if (lane == 0) s.offsets[obj] = off; }
+    if (lane == 0) s.nblocks[obj] = (uint32_t)nb;
+    if (off + nb * 64u > s.arena_bytes) return;          // host sized the arena; never write past it
+
+    const uint64_t key = s.seed ^ ((s.first_index + obj) * 0xD1342543DE82EF95ull);
+    const uint64_t bits = msg * 8u;
+    const uint64_t total = nb * 64u;
+    for (uint64_t c0 = (uint64_t)lane * 16u; c0 < total; c0 += 64u * 16u) {
+        uint32_t out[4] = {0, 0, 0, 0};
+        uint64_t cached_k = ~0ull, cached_w = 0;
+        for (uint32_t i = 0; i < 16; ++i) {
+            const uint64_t pos = c0 + i;
+            uint32_t byte;
+            if (pos < hl) {
+                if (pos < tl) byte = (uint8_t)s.type[pos];
+                else if (pos == tl) byte = ' ';
+                else if (pos == hl - 1) byte = 0;
+                else {                                    // decimal digit, most significant first
+                    uint32_t from_right = (uint32_t)(hl - 2 - pos);
+                    uint64_t v = len;
+                    for (uint32_t r = 0; r < from_right; ++r) v /= 10;
+                    byte = '0' + (uint32_t)(v % 10);
+                }
+            } else if (pos < msg) {
+                const uint64_t j = pos - hl, k = j >> 3;
+                if (k != cached_k) { cached_k = k; cached_w = mix64(key + (k + 1) * 0x9E3779B97F4A7C15ull); }
+                byte = (uint32_t)(cached_w >> (8 * (j & 7))) & 0xFFu;
+            } else if (pos == msg) byte = 0x80;
+            else if (pos >= total - 8) byte = (uint32_t)(bits >> (8 * (total - 1 - pos))) & 0xFFu;
+            else byte = 0;
+            out[i >> 2] |= byte << (8 * (i & 3));
+        }
+        *reinterpret_cast<uint4*>(s.arena + off + c0) = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+hipError_t launch_synth(const SynthSpec& s, hipStream_t stream)
+{
+    if (s.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_arena_kernel, dim3((s.n + 3u) / 4u), dim3(256), 0, stream, s);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------- compute ceiling --
+__global__ __launch_bounds__(256) void valu_peak_kernel(uint32_t* out, uint32_t n_lanes, uint32_t blocks)
+{
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    uint32_t h[5];
+    sha1_init(h);
+    uint32_t seedw[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) seedw[i] = gid * 0x9E3779B9u + i * 0x85EBCA6Bu;
+    for (uint32_t bl = 0; bl < blocks; ++bl) {
+        uint32_t w[16];
+        // Feed the previous digest back in so nothing is loop invariant; the
+        // 16 byte swaps stand in for the ones a real block costs.
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = bswap32(seedw[i] ^ h[i % 5]);
+        sha1_compress(h, w);
+    }
+    if (gid < n_lanes) out[gid] = h[0] ^ h[1] ^ h[2] ^ h[3] ^ h[4];
+}
+
+hipError_t launch_valu_peak(uint32_t* out, uint32_t n_lanes, uint32_t blocks_per_lane, hipStream_t stream)
+{
+    if (n_lanes == 0) return hipSuccess;
+    hipLaunchKernelGGL(valu_peak_kernel, dim3((n_lanes + 255u) / 256u), dim3(256), 0, stream, out, n_lanes,
+                       blocks_per_lane);
+    return hipGetLastError();
+}
+
+}  // namespace vit

@@ -1,0 +1,156 @@
+// packer.cpp — host side of the arena format: Git object framing, SHA-1
+// padding, length binning and the synthetic byte stream.  No device code.
+//
+// Arena slot of one object (all offsets multiples of 64):
+//   "<type> <decimal len>\0"   header, as reference src/commit.cpp:90 builds it
+//   content bytes              (src/commit.cpp:91 concatenates the two)
+//   0x80, zeros                FIPS 180-4 5.1.1 padding ...
+//   8-byte big-endian bit length of header+content, ending the last block
+// so that the device kernel only ever sees whole 64-byte blocks.
+#include "../../include/vit_hash.h"
+#include "host_util.h"
+#include "packer.h"
+
+#include <cstring>
+#include <numeric>
+
+namespace vit {
+
+uint32_t type_len_checked(const char* type)
+{
+    if (!type) return 0;
+    size_t l = std::strlen(type);
+    if (l == 0 || l > 8) return 0;           // "blob", "tree", "commit", "tag"
+    for (size_t i = 0; i < l; ++i)
+        if (type[i] == ' ' || type[i] == '\0') return 0;
+    return uint32_t(l);
+}
+
+uint32_t write_header(const char* type, uint32_t tl, uint64_t len, uint8_t* out)
+{
+    std::memcpy(out, type, tl);
+    out[tl] = ' ';
+    const uint32_t nd = decimal_digits(len);
+    uint64_t v = len;
+    for (uint32_t i = 0; i < nd; ++i) { out[tl + nd - i] = uint8_t('0' + v % 10); v /= 10; }
+    out[tl + 1 + nd] = 0;
+    return tl + 1 + nd + 1;
+}
+
+void pack_one(const char* type, uint32_t tl, const uint8_t* data, uint64_t len, uint8_t* slot, uint64_t nblocks)
+{
+    const uint32_t hl = write_header(type, tl, len, slot);
+    if (len) std::memcpy(slot + hl, data, size_t(len));
+    const uint64_t msg = hl + len, total = nblocks * 64;
+    slot[msg] = 0x80;
+    std::memset(slot + msg + 1, 0, size_t(total - 8 - (msg + 1)));
+    const uint64_t bits = msg * 8;
+    for (int i = 0; i < 8; ++i) slot[total - 8 + i] = uint8_t(bits >> (56 - 8 * i));
+}
+
+// LSD radix sort of indices by block count, descending, stable.
+bool bin_order(const uint32_t* nblocks, uint64_t n, uint32_t* order)
+{
+    bool uniform = true;
+    for (uint64_t i = 1; i < n && uniform; ++i) uniform = nblocks[i] == nblocks[0];
+    std::iota(order, order + n, 0u);
+    if (uniform) return false;
+    std::vector<uint32_t> tmp(n);
+    uint32_t* src = order;
+    uint32_t* dst = tmp.data();
+    uint32_t maxv = 0;
+    for (uint64_t i = 0; i < n; ++i) maxv = std::max(maxv, nblocks[i]);
+    for (int shift = 0; shift < 32 && (maxv >> shift); shift += 11) {
+        uint64_t count[2049] = {0};
+        // descending: bucket by the complemented digit
+        for (uint64_t i = 0; i < n; ++i) ++count[(2047u - ((nblocks[src[i]] >> shift) & 2047u)) + 1];
+        for (int d = 0; d < 2048; ++d) count[d + 1] += count[d];
+        for (uint64_t i = 0; i < n; ++i) dst[count[2047u - ((nblocks[src[i]] >> shift) & 2047u)]++] = src[i];
+        std::swap(src, dst);
+    }
+    if (src != order) std::memcpy(order, src, n * sizeof(uint32_t));
+    return true;
+}
+
+static inline uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+}  // namespace vit
+
+extern "C" {
+
+uint32_t vit_header_len(const char* type, uint64_t len)
+{
+    const uint32_t tl = vit::type_len_checked(type);
+    if (!tl) return 0;
+    return tl + 1 + vit::decimal_digits(len) + 1;
+}
+
+uint32_t vit_write_header(const char* type, uint64_t len, uint8_t* out)
+{
+    const uint32_t tl = vit::type_len_checked(type);
+    if (!tl || !out) return 0;
+    return vit::write_header(type, tl, len, out);
+}
+
+uint64_t vit_object_blocks(const char* type, uint64_t len)
+{
+    const uint32_t hl = vit_header_len(type, len);
+    if (!hl) return 0;
+    return (hl + len + 9 + 63) / 64;
+}
+
+int vit_arena_pack(const char* type, const uint8_t* const* data, const uint64_t* len, uint64_t n,
+                   void* arena, uint64_t arena_bytes, uint64_t* offsets, uint32_t* nblocks,
+                   uint64_t* used_bytes, int threads)
+{
+    const uint32_t tl = vit::type_len_checked(type);
+    if (!tl || (n && (!data || !len || !arena || !offsets || !nblocks))) return VIT_ERR_ARG;
+    std::vector<uint64_t> prefix(n + 1, 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (len[i] && !data[i]) return VIT_ERR_ARG;
+        const uint64_t nb = (tl + 1 + vit::decimal_digits(len[i]) + 1 + len[i] + 9 + 63) / 64;
+        if (nb > 0xFFFFFFFFull) return VIT_ERR_RANGE;
+        prefix[i + 1] = prefix[i] + nb;
+    }
+    const uint64_t total = prefix[n] * 64;
+    if (used_bytes) *used_bytes = total;
+    if (total > arena_bytes) return VIT_ERR_RANGE;
+    for (uint64_t i = 0; i < n; ++i) {
+        offsets[i] = prefix[i] * 64;
+        nblocks[i] = uint32_t(prefix[i + 1] - prefix[i]);
+    }
+    uint8_t* base = static_cast<uint8_t*>(arena);
+    if (total < (8u << 20)) threads = 1;
+    vit::parallel_ranges(n, threads, prefix.data(), [&](int, uint64_t b, uint64_t e) {
+        for (uint64_t i = b; i < e; ++i) vit::pack_one(type, tl, data[i], len[i], base + offsets[i], nblocks[i]);
+    });
+    return VIT_OK;
+}
+
+int vit_bin_order(const uint32_t* nblocks, uint64_t n, uint32_t* order)
+{
+    if (n && (!nblocks || !order)) return VIT_ERR_ARG;
+    if (n > 0xFFFFFFFFull) return VIT_ERR_RANGE;
+    return vit::bin_order(nblocks, n, order) ? 1 : 0;
+}
+
+void vit_synth_bytes(uint64_t seed, uint64_t index, uint8_t* dst, uint64_t len)
+{
+    const uint64_t key = seed ^ (index * 0xD1342543DE82EF95ull);
+    uint64_t i = 0, k = 0;
+    for (; i + 8 <= len; i += 8, ++k) {
+        const uint64_t w = vit::mix64(key + (k + 1) * 0x9E3779B97F4A7C15ull);
+        std::memcpy(dst + i, &w, 8);       // little-endian host
+    }
+    if (i < len) {
+        const uint64_t w = vit::mix64(key + (k + 1) * 0x9E3779B97F4A7C15ull);
+        std::memcpy(dst + i, &w, size_t(len - i));
+    }
+}
+
+}  // extern "C"

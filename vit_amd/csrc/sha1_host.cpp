@@ -1,0 +1,151 @@
+// sha1_host.cpp — streaming SHA-1 on a host core (see sha1_host.h for its role).
+#include "sha1_host.h"
+
+#include <cstdio>
+#include <cstring>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+namespace vit {
+namespace {
+
+inline uint32_t rol(uint32_t x, int n) { return (x << n) | (x >> (32 - n)); }
+inline uint32_t load_be(const uint8_t* p)
+{
+    return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | uint32_t(p[3]);
+}
+
+// Portable block function: rolling 16-word schedule, rounds in groups by phase.
+void blocks_portable(uint32_t h[5], const uint8_t* p, size_t nblocks)
+{
+    while (nblocks--) {
+        uint32_t w[16];
+        for (int i = 0; i < 16; ++i) w[i] = load_be(p + 4 * i);
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4];
+        auto sched = [&](int t) {
+            uint32_t x = w[(t - 3) & 15] ^ w[(t - 8) & 15] ^ w[(t - 14) & 15] ^ w[t & 15];
+            return w[t & 15] = rol(x, 1);
+        };
+        auto step = [&](uint32_t f, uint32_t k, uint32_t wt) {
+            uint32_t tmp = rol(a, 5) + f + e + k + wt;
+            e = d; d = c; c = rol(b, 30); b = a; a = tmp;
+        };
+        int t = 0;
+        for (; t < 16; ++t) step(d ^ (b & (c ^ d)), 0x5A827999u, w[t]);
+        for (; t < 20; ++t) step(d ^ (b & (c ^ d)), 0x5A827999u, sched(t));
+        for (; t < 40; ++t) step(b ^ c ^ d, 0x6ED9EBA1u, sched(t));
+        for (; t < 60; ++t) step((b & c) | (d & (b | c)), 0x8F1BBCDCu, sched(t));
+        for (; t < 80; ++t) step(b ^ c ^ d, 0xCA62C1D6u, sched(t));
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e;
+        p += 64;
+    }
+}
+
+#if defined(__x86_64__)
+// x86 SHA extensions: four rounds per sha1rnds4, schedule by sha1msg1/sha1msg2.
+__attribute__((target("sha,sse4.1,ssse3")))
+void blocks_shani(uint32_t h[5], const uint8_t* p, size_t nblocks)
+{
+    const __m128i bswap = _mm_set_epi64x(0x0001020304050607ll, 0x08090a0b0c0d0e0fll);
+    __m128i abcd = _mm_shuffle_epi32(_mm_loadu_si128(reinterpret_cast<const __m128i*>(h)), 0x1B);
+    __m128i e = _mm_set_epi32(int(h[4]), 0, 0, 0);
+
+    while (nblocks--) {
+        const __m128i abcd0 = abcd, e0 = e;
+        __m128i m[4];
+        for (int i = 0; i < 4; ++i)
+            m[i] = _mm_shuffle_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p + 16 * i)), bswap);
+
+        __m128i prev = abcd, cur;
+        // Group g covers rounds 4g..4g+3 with round function g/5; after using
+        // m[g&3] it is replaced by the words of group g+4.
+#define VIT_G(g)                                                                              \
+        cur = (g) == 0 ? _mm_add_epi32(e, m[0]) : _mm_sha1nexte_epu32(prev, m[(g) & 3]);          \
+        prev = abcd;                                                                          \
+        abcd = _mm_sha1rnds4_epu32(abcd, cur, (g) / 5);                                        \
+        if ((g) < 16)                                                                         \
+            m[(g) & 3] = _mm_sha1msg2_epu32(                                                   \
+                _mm_xor_si128(_mm_sha1msg1_epu32(m[(g) & 3], m[((g) + 1) & 3]), m[((g) + 2) & 3]), \
+                m[((g) + 3) & 3]);
+        VIT_G(0)  VIT_G(1)  VIT_G(2)  VIT_G(3)  VIT_G(4)  VIT_G(5)  VIT_G(6)  VIT_G(7)  VIT_G(8)  VIT_G(9)
+        VIT_G(10) VIT_G(11) VIT_G(12) VIT_G(13) VIT_G(14) VIT_G(15) VIT_G(16) VIT_G(17) VIT_G(18) VIT_G(19)
+#undef VIT_G
+        e = _mm_sha1nexte_epu32(prev, e0);
+        abcd = _mm_add_epi32(abcd, abcd0);
+        p += 64;
+    }
+    _mm_storeu_si128(reinterpret_cast<__m128i*>(h), _mm_shuffle_epi32(abcd, 0x1B));
+    h[4] = uint32_t(_mm_extract_epi32(e, 3));
+}
+
+bool cpu_has_sha()
+{
+    static const bool yes = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") &&
+                            __builtin_cpu_supports("ssse3");
+    return yes;
+}
+#else
+bool cpu_has_sha() { return false; }
+#endif
+
+void blocks(uint32_t h[5], const uint8_t* p, size_t n)
+{
+#if defined(__x86_64__)
+    if (cpu_has_sha()) { blocks_shani(h, p, n); return; }
+#endif
+    blocks_portable(h, p, n);
+}
+
+}  // namespace
+
+bool HostSha1::accelerated() { return cpu_has_sha(); }
+
+HostSha1::HostSha1() : nbytes_(0)
+{
+    h_[0] = 0x67452301u; h_[1] = 0xEFCDAB89u; h_[2] = 0x98BADCFEu; h_[3] = 0x10325476u; h_[4] = 0xC3D2E1F0u;
+}
+
+void HostSha1::update(const void* data, size_t len)
+{
+    const uint8_t* p = static_cast<const uint8_t*>(data);
+    size_t have = size_t(nbytes_ & 63);
+    nbytes_ += len;
+    if (have) {
+        size_t take = 64 - have < len ? 64 - have : len;
+        std::memcpy(buf_ + have, p, take);
+        p += take; len -= take; have += take;
+        if (have < 64) return;
+        blocks(h_, buf_, 1);
+    }
+    if (len >= 64) { blocks(h_, p, len / 64); p += len & ~size_t(63); len &= 63; }
+    if (len) std::memcpy(buf_, p, len);
+}
+
+void HostSha1::finish(uint8_t out[20])
+{
+    const uint64_t bits = nbytes_ * 8;
+    size_t have = size_t(nbytes_ & 63);
+    buf_[have++] = 0x80;
+    if (have > 56) { std::memset(buf_ + have, 0, 64 - have); blocks(h_, buf_, 1); have = 0; }
+    std::memset(buf_ + have, 0, 56 - have);
+    for (int i = 0; i < 8; ++i) buf_[56 + i] = uint8_t(bits >> (56 - 8 * i));
+    blocks(h_, buf_, 1);
+    for (int i = 0; i < 5; ++i) {
+        out[4 * i] = uint8_t(h_[i] >> 24); out[4 * i + 1] = uint8_t(h_[i] >> 16);
+        out[4 * i + 2] = uint8_t(h_[i] >> 8); out[4 * i + 3] = uint8_t(h_[i]);
+    }
+}
+
+void host_object_id(const char* type, const uint8_t* content, uint64_t len, uint8_t out[20])
+{
+    char hdr[40];
+    int hl = std::snprintf(hdr, sizeof hdr, "%s %llu", type, static_cast<unsigned long long>(len)) + 1;
+    HostSha1 s;
+    s.update(hdr, size_t(hl));
+    s.update(content, size_t(len));
+    s.finish(out);
+}
+
+}  // namespace vit

@@ -1,0 +1,261 @@
+"""Python view of the C ABI (include/vit_hash.h), used by the tests and bench.py.
+
+Every method is a direct call into libvit_hash.so; nothing is computed here.
+Digests come back as numpy uint8 arrays of shape (n, 20), in input order —
+the raw bytes the reference turns into hex with hashToHexString
+(reference src/commit.cpp:52-59,95).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+
+KERNEL_LDS = 0
+KERNEL_LANE = 1
+
+
+class VitError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__("vit error %d: %s" % (code, text))
+        self.code = code
+
+
+def header_len(type_, length):
+    return _abi.load().vit_header_len(type_.encode(), length)
+
+
+def object_blocks(type_, length):
+    return _abi.load().vit_object_blocks(type_.encode(), length)
+
+
+def synth_bytes(seed, index, length):
+    out = np.empty(max(length, 1), dtype=np.uint8)
+    _abi.load().vit_synth_bytes(seed, index, out.ctypes.data, length)
+    return out[:length].tobytes()
+
+
+def _as_ptr_arrays(blobs):
+    """list of bytes-like -> (keepalive, uint8* array, uint64 lengths array)."""
+    n = len(blobs)
+    ptrs = (C.c_void_p * max(n, 1))()
+    lens = np.empty(max(n, 1), dtype=np.uint64)
+    keep = []
+    for i, b in enumerate(blobs):
+        if isinstance(b, np.ndarray):
+            a = np.ascontiguousarray(b, dtype=np.uint8)
+        else:
+            a = np.frombuffer(bytes(b), dtype=np.uint8)
+        keep.append(a)
+        ptrs[i] = a.ctypes.data if a.size else None
+        lens[i] = a.size
+    return keep, ptrs, lens
+
+
+def pack_arena(type_, blobs, arena=None, threads=4):
+    """Host-only packing (vit_arena_pack).  Returns (arena, offsets, nblocks, used)."""
+    lib = _abi.load()
+    keep, ptrs, lens = _as_ptr_arrays(blobs)
+    n = len(blobs)
+    need = sum(int(lib.vit_object_blocks(type_.encode(), int(l))) for l in lens[:n]) * 64
+    if arena is None:
+        arena = np.zeros(max(need, 64), dtype=np.uint8)
+    offsets = np.zeros(max(n, 1), dtype=np.uint64)
+    nblocks = np.zeros(max(n, 1), dtype=np.uint32)
+    used = C.c_uint64(0)
+    rc = lib.vit_arena_pack(type_.encode(), ptrs, lens.ctypes.data, n, arena.ctypes.data, arena.size,
+                            offsets.ctypes.data, nblocks.ctypes.data, C.byref(used), threads)
+    if rc != 0:
+        raise VitError(rc, "vit_arena_pack")
+    return arena, offsets[:n], nblocks[:n], used.value
+
+
+def bin_order(nblocks):
+    nblocks = np.ascontiguousarray(nblocks, dtype=np.uint32)
+    order = np.empty(max(len(nblocks), 1), dtype=np.uint32)
+    rc = _abi.load().vit_bin_order(nblocks.ctypes.data, len(nblocks), order.ctypes.data)
+    if rc < 0:
+        raise VitError(rc, "vit_bin_order")
+    return order[:len(nblocks)], bool(rc)
+
+
+class DeviceBuffer:
+    """Device memory owned through vit_device_alloc/free."""
+
+    def __init__(self, hasher, dev, nbytes):
+        self.h, self.dev, self.nbytes = hasher, dev, int(nbytes)
+        p = C.c_void_p()
+        hasher._check(hasher.lib.vit_device_alloc(hasher.handle, dev, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        self.h._check(self.h.lib.vit_device_upload(self.h.handle, self.dev, self.ptr, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, dtype=np.uint8, nbytes=None, offset=0):
+        nbytes = self.nbytes - offset if nbytes is None else int(nbytes)
+        out = np.empty(nbytes, dtype=np.uint8)
+        self.h._check(self.h.lib.vit_device_download(self.h.handle, self.dev, out.ctypes.data,
+                                                     self.ptr + offset, nbytes))
+        return out.view(dtype)
+
+    def free(self):
+        if self.ptr:
+            self.h.lib.vit_device_free(self.h.handle, self.dev, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Hasher:
+    """vit_hasher handle.  devices=None: every visible GPU."""
+
+    def __init__(self, devices=(0,)):
+        self.lib = _abi.load()
+        ids = list(devices) if devices is not None else []
+        arr = (C.c_int * max(len(ids), 1))(*ids)
+        h = C.c_void_p()
+        rc = self.lib.vit_hasher_create(arr if ids else None, len(ids), C.byref(h))
+        if rc != 0:
+            raise VitError(rc, self.lib.vit_last_error(None).decode())
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.vit_hasher_destroy(self.handle)
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise VitError(rc, self.lib.vit_last_error(self.handle).decode())
+
+    @property
+    def device_count(self):
+        return self.lib.vit_hasher_device_count(self.handle)
+
+    def set_option(self, name, value):
+        self._check(self.lib.vit_hasher_set_option(self.handle, name.encode(), int(value)))
+
+    def stat(self, name):
+        v = C.c_uint64(0)
+        self._check(self.lib.vit_hasher_get_stat(self.handle, name.encode(), C.byref(v)))
+        return v.value
+
+    # -- host-memory batches ------------------------------------------------
+    def hash_objects(self, type_, blobs):
+        keep, ptrs, lens = _as_ptr_arrays(blobs)
+        n = len(blobs)
+        out = np.zeros((max(n, 1), 20), dtype=np.uint8)
+        self._check(self.lib.vit_hash_objects(self.handle, type_.encode(), ptrs, lens.ctypes.data, n,
+                                              out.ctypes.data))
+        return out[:n]
+
+    def hash_blobs(self, blobs):
+        keep, ptrs, lens = _as_ptr_arrays(blobs)
+        n = len(blobs)
+        out = np.zeros((max(n, 1), 20), dtype=np.uint8)
+        self._check(self.lib.vit_hash_blobs(self.handle, ptrs, lens.ctypes.data, n, out.ctypes.data))
+        return out[:n]
+
+    def hash_arena(self, arena, offsets, nblocks, dev=0, arena_bytes=None):
+        arena = np.ascontiguousarray(arena, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        nblocks = np.ascontiguousarray(nblocks, dtype=np.uint32)
+        n = len(offsets)
+        out = np.zeros((max(n, 1), 20), dtype=np.uint8)
+        self._check(self.lib.vit_hash_arena(self.handle, dev, arena.ctypes.data,
+                                            arena.size if arena_bytes is None else arena_bytes,
+                                            offsets.ctypes.data, nblocks.ctypes.data, n, out.ctypes.data))
+        return out[:n]
+
+    # -- device-resident batches ---------------------------------------------
+    def alloc(self, nbytes, dev=0):
+        return DeviceBuffer(self, dev, nbytes)
+
+    def sync(self, dev=0):
+        self._check(self.lib.vit_device_sync(self.handle, dev))
+
+    def device_status(self, dev=0):
+        s = C.c_uint32(0)
+        self._check(self.lib.vit_device_status(self.handle, dev, C.byref(s)))
+        return s.value
+
+    def synth_arena(self, type_, seed, first_index, n, len_each, dev=0, lens=None):
+        """Generate a framed synthetic arena on the device.  Returns a dict of
+        DeviceBuffers (arena, offsets, nblocks, digests) plus sizes."""
+        if lens is None:
+            nb = object_blocks(type_, len_each)
+            arena_bytes = nb * 64 * n
+            d_lens = None
+            offsets_host = None
+        else:
+            lens = np.ascontiguousarray(lens, dtype=np.uint64)
+            assert len(lens) == n
+            nbs = np.array([object_blocks(type_, int(l)) for l in lens], dtype=np.uint64) \
+                if n < 200000 else _blocks_vec(type_, lens)
+            offsets_host = np.concatenate([[0], np.cumsum(nbs * 64)]).astype(np.uint64)
+            arena_bytes = int(offsets_host[-1])
+            offsets_host = offsets_host[:-1].copy()
+            d_lens = self.alloc(8 * n, dev).upload(lens)
+        arena = self.alloc(max(arena_bytes, 64), dev)
+        offsets = self.alloc(8 * max(n, 1), dev)
+        nblocks = self.alloc(4 * max(n, 1), dev)
+        digests = self.alloc(20 * max(n, 1), dev)
+        if offsets_host is not None:
+            offsets.upload(offsets_host)
+        self._check(self.lib.vit_synth_arena_device(
+            self.handle, dev, type_.encode(), seed, first_index, n, len_each,
+            d_lens.ptr if d_lens else None, offsets.ptr, nblocks.ptr, arena.ptr, arena_bytes, None))
+        self.sync(dev)
+        return dict(arena=arena, offsets=offsets, nblocks=nblocks, digests=digests, n=n,
+                    arena_bytes=arena_bytes, lens=d_lens, dev=dev)
+
+    def hash_device(self, batch, order=None):
+        """Launch on a batch from synth_arena(); returns digests as (n, 20)."""
+        self._check(self.lib.vit_hash_arena_device(
+            self.handle, batch["dev"], batch["arena"].ptr, batch["arena_bytes"], batch["offsets"].ptr,
+            batch["nblocks"].ptr, order.ptr if order is not None else None, batch["n"],
+            batch["digests"].ptr, None))
+        self.sync(batch["dev"])
+        return batch["digests"].download(np.uint8, 20 * batch["n"]).reshape(-1, 20)
+
+    def time_hash_device(self, batch, order=None, warmup=1, iters=5):
+        ms = (C.c_float * max(iters, 1))()
+        self._check(self.lib.vit_time_hash_device(
+            self.handle, batch["dev"], batch["arena"].ptr, batch["arena_bytes"], batch["offsets"].ptr,
+            batch["nblocks"].ptr, order.ptr if order is not None else None, batch["n"],
+            batch["digests"].ptr, warmup, iters, ms))
+        return [float(ms[i]) for i in range(iters)]
+
+    def valu_peak(self, n_lanes, blocks_per_lane, iters=3, dev=0):
+        ms = C.c_float(0)
+        self._check(self.lib.vit_valu_peak(self.handle, dev, n_lanes, blocks_per_lane, iters, C.byref(ms)))
+        return float(ms.value)
+
+
+def _blocks_vec(type_, lens):
+    """Vectorised vit_object_blocks for large length arrays."""
+    lens = lens.astype(np.uint64)
+    digits = np.ones(len(lens), dtype=np.uint64)
+    for k in range(1, 20):
+        digits += (lens >= np.uint64(10 ** k)).astype(np.uint64)
+    hl = np.uint64(len(type_) + 2) + digits
+    return (hl + lens + np.uint64(9 + 63)) // np.uint64(64)
