@@ -122,6 +122,13 @@ int vit_arena_pack(const char *type, const uint8_t *const *data, const uint64_t 
  * (order is then the identity and may be omitted), negative on error. */
 int vit_bin_order(const uint32_t *nblocks, uint64_t n, uint32_t *order);
 
+/* The multi-GPU partition vit_hash_objects applies: queue_of[i] = device queue
+ * (0 .. n_queues-1) that hashes object i, balanced by block count (bytes), not
+ * by object count; objects that are large against a fair share are placed
+ * first, longest to the least loaded queue.  Host-only; needs no device.  The
+ * reference is single-threaded and has no counterpart (src/commit.cpp:143). */
+int vit_shard_plan(const uint32_t *nblocks, uint64_t n, int n_queues, uint32_t *queue_of);
+
 /* Hash a packed arena that lives in host memory on device queue `dev`
  * (0 <= dev < vit_hasher_device_count).  Offsets and block counts are checked
  * against arena_bytes on the host before anything is launched. */

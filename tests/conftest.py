@@ -1,0 +1,71 @@
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_objects():
+    return json.load(open(os.path.join(GOLDEN, "objects.json")))
+
+
+@pytest.fixture(scope="session")
+def golden_trees():
+    return json.load(open(os.path.join(GOLDEN, "trees.json")))
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pyoracle
+    pyoracle.lib()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def hasher():
+    """One hasher on GPU 0 for the whole GPU session (fails loudly without a GPU)."""
+    import vit_amd
+    h = vit_amd.Hasher((0,))
+    yield h
+    h.close()
+
+
+def materialize(spec, root, oracle):
+    """Write a worktree from a golden spec: (path, seed, index, length[, 'x']) or (dir, None)."""
+    for item in spec:
+        path = os.path.join(root, item[0])
+        if item[1] is None:
+            os.makedirs(path, exist_ok=True)
+            continue
+        os.makedirs(os.path.dirname(path) or root, exist_ok=True)
+        with open(path, "wb") as f:
+            f.write(oracle.synth_bytes(item[1], item[2], item[3]))
+        if len(item) > 4 and item[4] == "x":
+            os.chmod(path, 0o755)
+
+
+def c1_spec(seed):
+    return [("d%02d/f%04d.bin" % (i // 100, i), seed, i, 4096) for i in range(1000)]
+
+
+@pytest.fixture(scope="session")
+def worktrees(tmp_path_factory, golden_trees, oracle):
+    """Every golden worktree materialised once: name -> directory."""
+    out = {}
+    for name, rec in golden_trees.items():
+        d = tmp_path_factory.mktemp("wt_" + name)
+        spec = c1_spec(rec["seed"]) if rec["spec"] == "c1" else rec["spec"]
+        materialize(spec, str(d), oracle)
+        out[name] = str(d)
+    return out

@@ -1,0 +1,162 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol the
+header declares, and its host-only parts (framing, packing, binning, sharding,
+the host-lane SHA-1) agree with the oracle.  No GPU compute here."""
+import ctypes as C
+import hashlib
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from vit_amd import _abi
+    return _abi.load()
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "vit_hash.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(vit_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from vit_amd import _abi
+    names = declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "libvit_hash.so does not export %s" % n
+        assert n in _abi.SIGNATURES, "no ctypes prototype for %s" % n
+    assert sorted(_abi.SIGNATURES) == names
+
+
+def test_header_and_block_count(lib, oracle):
+    for t in ("blob", "tree", "commit"):
+        for L in (0, 1, 9, 10, 99, 100, 4095, 4096, 99999, 100000, (1 << 32) + 5, 10 ** 18):
+            hdr = oracle.header(t, L)
+            assert lib.vit_header_len(t.encode(), L) == len(hdr)
+            buf = C.create_string_buffer(32)
+            assert lib.vit_write_header(t.encode(), L, buf) == len(hdr)
+            assert buf.raw[:len(hdr)] == hdr
+            assert lib.vit_object_blocks(t.encode(), L) == (len(hdr) + L + 9 + 63) // 64
+    assert lib.vit_object_blocks(b"blob", 4096) == 65          # the BASELINE config: 65 blocks per 4 KiB blob
+    assert lib.vit_header_len(b"", 1) == 0 and lib.vit_header_len(b"has space", 1) == 0
+
+
+def test_pack_layout_is_what_sha1_compresses(oracle):
+    """A packed slot = framed message + FIPS 180-4 padding: hashing its blocks with
+    a raw compression loop must give the Git id."""
+    import vit_amd
+    lens = list(range(0, 130)) + [4095, 4096, 4097, 65530]
+    blobs = [oracle.synth_bytes(21, i, L) for i, L in enumerate(lens)]
+    for t in ("blob", "tree", "commit"):
+        arena, off, nb, used = vit_amd.pack_arena(t, blobs, threads=3)
+        assert used == int(nb.astype(np.uint64).sum()) * 64
+        assert (off % 64 == 0).all()
+        assert (off[1:] == off[:-1] + nb[:-1].astype(np.uint64) * 64).all()
+        for i, b in enumerate(blobs):
+            slot = arena[int(off[i]):int(off[i]) + int(nb[i]) * 64].tobytes()
+            framed = oracle.header(t, len(b)) + b
+            assert slot[:len(framed)] == framed
+            assert slot[len(framed)] == 0x80
+            assert not any(slot[len(framed) + 1:-8])
+            assert int.from_bytes(slot[-8:], "big") == 8 * len(framed)
+            assert int(nb[i]) == (len(framed) + 9 + 63) // 64
+
+
+def test_pack_rejects_small_arena_and_bad_args(lib):
+    import vit_amd
+    blobs = [b"x" * 100]
+    with pytest.raises(vit_amd.VitError) as e:
+        vit_amd.pack_arena("blob", blobs, arena=np.zeros(64, dtype=np.uint8))
+    assert e.value.code == -4
+    with pytest.raises(vit_amd.VitError):
+        vit_amd.pack_arena("two words", blobs)
+    arena, off, nb, used = vit_amd.pack_arena("blob", [])
+    assert used == 0 and len(off) == 0
+
+
+def test_bin_order_longest_first_and_stable():
+    import vit_amd
+    rng = np.random.default_rng(1)
+    nb = rng.integers(1, 5000, size=10000).astype(np.uint32)
+    nb[::97] = 1 << 22                                     # a few very long ones (third radix digit)
+    order, differs = vit_amd.bin_order(nb)
+    assert differs
+    assert sorted(order.tolist()) == list(range(len(nb)))
+    s = nb[order]
+    assert (s[:-1] >= s[1:]).all()
+    same = s[:-1] == s[1:]
+    assert (order[:-1][same] < order[1:][same]).all()      # ties keep index order
+    order, differs = vit_amd.bin_order(np.full(1000, 65, dtype=np.uint32))
+    assert not differs and (order == np.arange(1000)).all()
+
+
+def test_shard_plan_balances_bytes_not_counts(lib):
+    rng = np.random.default_rng(2)
+    # adversarial skew: 4 huge objects + a million tiny ones
+    nb = np.concatenate([np.full(4, 33554433, dtype=np.uint32), rng.integers(1, 6, size=200000).astype(np.uint32)])
+    rng.shuffle(nb)
+    for q in (1, 2, 4, 8):
+        plan = np.empty(len(nb), dtype=np.uint32)
+        assert lib.vit_shard_plan(nb.ctypes.data, len(nb), q, plan.ctypes.data) == 0
+        assert plan.max() < q
+        load = np.bincount(plan, weights=nb.astype(np.float64), minlength=q)
+        if q <= 4:                                        # 4 giants fit 1, 2 or 4 queues evenly
+            assert load.max() <= 1.02 * load.sum() / q
+        huge = plan[nb == 33554433]
+        assert len(set(huge.tolist())) == min(q, 4)        # the giants land on different queues
+    # uniform sizes: contiguous, equal shares
+    nb = np.full(100000, 65, dtype=np.uint32)
+    plan = np.empty(len(nb), dtype=np.uint32)
+    assert lib.vit_shard_plan(nb.ctypes.data, len(nb), 8, plan.ctypes.data) == 0
+    counts = np.bincount(plan, minlength=8)
+    assert counts.max() - counts.min() <= 16
+    assert (np.diff(plan.astype(np.int64)) >= 0).all()
+
+
+def test_host_lane_sha1_matches_reference_golden(lib, oracle, golden_objects):
+    g = golden_objects["blobs"]
+    for L, want in g["ids"]:
+        data = oracle.synth_bytes(g["seed"], L, L)
+        out = C.create_string_buffer(20)
+        arr = np.frombuffer(data, dtype=np.uint8) if L else np.zeros(1, dtype=np.uint8)
+        assert lib.vit_host_object_id(b"blob", arr.ctypes.data, L, out) == 0
+        assert out.raw.hex() == want, L
+    out = C.create_string_buffer(20)
+    assert lib.vit_host_object_id(b"tree", None, 0, out) == 0
+    assert out.raw.hex() == golden_objects["kats"]["git_empty_tree"]
+    assert lib.vit_host_object_id(b"blob", None, 5, out) == -1
+
+
+def test_library_synth_bytes_is_the_shared_generator(oracle):
+    import vit_amd
+    for L in (0, 1, 8, 9, 4096, 4099):
+        assert vit_amd.synth_bytes(0x5EED0002, 999999, L) == oracle.synth_bytes(0x5EED0002, 999999, L)
+
+
+def test_create_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import vit_amd
+    with pytest.raises(vit_amd.VitError) as e:
+        vit_amd.Hasher((0,))
+    assert e.value.code == -5
+    assert "no CPU path" in str(e.value)
+
+
+def test_product_does_not_use_the_oracle():
+    """Nothing under vit_amd/ (the shipped path) may import, link or call oracle/."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "vit_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp")):
+                text = open(os.path.join(base, f), errors="replace").read()
+                if re.search(r"\boracle\b|vit_oracle|liboracle|libvitref", text):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad

@@ -1,0 +1,225 @@
+"""Parity of the HIP path with the oracle and with the reference's golden ids.
+Every call goes through the C ABI (libvit_hash.so).  Bar: bit-exact digests."""
+import concurrent.futures
+import hashlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+KERNELS = [0, 1]      # VIT_KERNEL_LDS, VIT_KERNEL_LANE
+
+
+def ids_of(oracle, type_, blobs):
+    return np.array([np.frombuffer(oracle.object_id(type_, b), dtype=np.uint8) for b in blobs]).reshape(-1, 20)
+
+
+def assert_same(got, want, labels):
+    bad = np.nonzero((got != want).any(axis=1))[0]
+    assert len(bad) == 0, "digests differ at %s" % [labels[i] for i in bad[:12]]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_golden_blob_ids_from_the_reference(hasher, oracle, golden_objects, kernel):
+    g = golden_objects["blobs"]
+    hasher.set_option("kernel", kernel)
+    lens = [L for L, _ in g["ids"]]
+    blobs = [oracle.synth_bytes(g["seed"], L, L) for L in lens]
+    got = hasher.hash_blobs(blobs)
+    want = np.array([np.frombuffer(bytes.fromhex(x), dtype=np.uint8) for _, x in g["ids"]])
+    assert_same(got, want, lens)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_golden_typed_objects(hasher, oracle, golden_objects, kernel):
+    g = golden_objects["typed"]
+    hasher.set_option("kernel", kernel)
+    for t in ("blob", "tree", "commit"):
+        rows = [(L, x) for tt, L, x in g["ids"] if tt == t]
+        got = hasher.hash_objects(t, [oracle.synth_bytes(g["seed"], L, L) for L, _ in rows])
+        want = np.array([np.frombuffer(bytes.fromhex(x), dtype=np.uint8) for _, x in rows])
+        assert_same(got, want, [(t, L) for L, _ in rows])
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_known_answers(hasher, golden_objects, kernel):
+    k = golden_objects["kats"]
+    hasher.set_option("kernel", kernel)
+    got = hasher.hash_blobs([b"", k["git_hello_blob"][0].encode()])
+    assert got[0].tobytes().hex() == k["git_empty_blob"]
+    assert got[1].tobytes().hex() == k["git_hello_blob"][1]
+    assert hasher.hash_objects("tree", [b""])[0].tobytes().hex() == k["git_empty_tree"]
+
+
+def test_empty_batch_and_empty_objects(hasher, oracle):
+    assert hasher.hash_blobs([]).shape == (0, 20)
+    got = hasher.hash_blobs([b""] * 200)
+    assert (got == np.frombuffer(oracle.blob_id(b""), dtype=np.uint8)).all()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_ragged_batch_every_wave_position(hasher, oracle, kernel):
+    """Lengths chosen so that waves mix 1..70-block objects, batch sizes that are
+    not multiples of 64, and binning reorders everything."""
+    hasher.set_option("kernel", kernel)
+    rng = np.random.default_rng(1234 + kernel)
+    for n in (1, 63, 64, 65, 1000, 4099):
+        lens = rng.integers(0, 4500, size=n).tolist()
+        blobs = [oracle.synth_bytes(42, i, L) for i, L in enumerate(lens)]
+        got = hasher.hash_blobs(blobs)
+        assert_same(got, ids_of(oracle, "blob", blobs), lens)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_skewed_batch_with_large_objects(hasher, oracle, kernel):
+    """A few multi-MiB objects among tiny ones, forced onto the GPU lanes
+    (host_threshold 0), then with the host lane taking the large ones."""
+    hasher.set_option("kernel", kernel)
+    lens = [3 << 20, 5, 0, (2 << 20) + 17, 200, 64, 1 << 20] + [i % 300 for i in range(500)]
+    blobs = [oracle.synth_bytes(43, i, L) for i, L in enumerate(lens)]
+    want = ids_of(oracle, "blob", blobs)
+    hasher.set_option("host_threshold_bytes", 0)
+    g0, h0 = hasher.stat("objects_gpu"), hasher.stat("objects_host")
+    assert_same(hasher.hash_blobs(blobs), want, lens)
+    assert hasher.stat("objects_gpu") - g0 == len(lens) and hasher.stat("objects_host") == h0
+    hasher.set_option("host_threshold_bytes", 1 << 20)
+    g0, h0 = hasher.stat("objects_gpu"), hasher.stat("objects_host")
+    assert_same(hasher.hash_blobs(blobs), want, lens)
+    assert hasher.stat("objects_host") - h0 == 2 and hasher.stat("objects_gpu") - g0 == len(lens) - 2
+    hasher.set_option("host_threshold_bytes", 16 << 20)
+
+
+def test_chunked_pipeline_matches_single_chunk(hasher, oracle):
+    """Force many small staging chunks so both pinned buffers cycle several times."""
+    lens = [(i * 37) % 5000 for i in range(3000)]
+    blobs = [oracle.synth_bytes(44, i, L) for i, L in enumerate(lens)]
+    want = ids_of(oracle, "blob", blobs)
+    hasher.set_option("chunk_bytes", 1 << 20)
+    l0 = hasher.stat("launches")
+    got = hasher.hash_blobs(blobs)
+    assert hasher.stat("launches") - l0 >= 5
+    hasher.set_option("chunk_bytes", 256 << 20)
+    assert_same(got, want, lens)
+
+
+def test_prepacked_arena_and_input_checks(hasher, oracle):
+    import vit_amd
+    lens = [0, 10, 55, 56, 4096, 100000]
+    blobs = [oracle.synth_bytes(45, i, L) for i, L in enumerate(lens)]
+    arena, off, nb, used = vit_amd.pack_arena("blob", blobs)
+    assert_same(hasher.hash_arena(arena, off, nb), ids_of(oracle, "blob", blobs), lens)
+    # out-of-range and misaligned input is rejected on the host, nothing is launched
+    bad_off = off.copy(); bad_off[3] = used
+    with pytest.raises(vit_amd.VitError) as e:
+        hasher.hash_arena(arena, bad_off, nb)
+    assert e.value.code == -4
+    bad_off = off.copy(); bad_off[2] += 4
+    with pytest.raises(vit_amd.VitError):
+        hasher.hash_arena(arena, bad_off, nb)
+    bad_nb = nb.copy(); bad_nb[-1] += 1000
+    with pytest.raises(vit_amd.VitError):
+        hasher.hash_arena(arena, off, bad_nb)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_device_kernel_flags_bad_input_instead_of_faulting(hasher, oracle, kernel):
+    """Device-resident batches cannot be checked on the host; the kernel must skip
+    objects that would read outside the arena and raise a status bit."""
+    hasher.set_option("kernel", kernel)
+    b = hasher.synth_arena("blob", 7, 0, 300, 1000)
+    good = hasher.hash_device(b)
+    assert hasher.device_status() == 0
+    off = b["offsets"].download(np.uint64, 8 * 300)
+    bad = off.copy()
+    bad[17] = np.uint64(b["arena_bytes"])            # starts at the end: out of bounds
+    bad[40] += np.uint64(8)                          # misaligned
+    b["offsets"].upload(bad)
+    got = hasher.hash_device(b)
+    assert hasher.device_status() == (1 | 2)
+    assert hasher.device_status() == 0               # reading clears it
+    keep = np.ones(300, dtype=bool); keep[[17, 40]] = False
+    assert (got[keep] == good[keep]).all()
+    b["offsets"].upload(off)
+    order = hasher.alloc(4 * 300)
+    o = np.arange(300, dtype=np.uint32)[::-1].copy(); o[5] = 1000
+    order.upload(o)
+    hasher.hash_device(b, order=order)
+    assert hasher.device_status() == 4
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_generator_and_device_path_on_ragged_lengths(hasher, oracle, kernel):
+    """Device generator == host packer byte for byte, and the device-resident
+    launch (with and without binning order) gives the oracle's ids."""
+    import vit_amd
+    hasher.set_option("kernel", kernel)
+    rng = np.random.default_rng(5)
+    lens = np.concatenate([rng.integers(0, 300, 700), rng.integers(3000, 70000, 30), [0, 9, 10, 99, 100]]).astype(np.uint64)
+    n = len(lens)
+    b = hasher.synth_arena("blob", 0x5EED0003, 100, n, 0, lens=lens)
+    blobs = [oracle.synth_bytes(0x5EED0003, 100 + i, int(L)) for i, L in enumerate(lens)]
+    arena, off, nb, used = vit_amd.pack_arena("blob", blobs)
+    assert used == b["arena_bytes"]
+    assert (b["arena"].download(np.uint8, used) == arena[:used]).all()
+    assert (b["nblocks"].download(np.uint32, 4 * n) == nb).all()
+    want = ids_of(oracle, "blob", blobs)
+    assert_same(hasher.hash_device(b), want, lens.tolist())
+    order_host, differs = vit_amd.bin_order(nb)
+    assert differs
+    order = hasher.alloc(4 * n).upload(order_host)
+    b["digests"].upload(np.zeros(20 * n, dtype=np.uint8))
+    assert_same(hasher.hash_device(b, order=order), want, lens.tolist())
+    assert hasher.device_status() == 0
+
+
+def test_two_queues_on_one_gpu_shard_and_agree(oracle):
+    """The multi-device path (one worker per queue, byte-balanced shards) exercised
+    on a single GPU by naming it twice."""
+    import vit_amd
+    lens = [(i * 53) % 9000 for i in range(5000)] + [2 << 20, 3 << 20]
+    blobs = [oracle.synth_bytes(46, i, L) for i, L in enumerate(lens)]
+    want = ids_of(oracle, "blob", blobs)
+    with vit_amd.Hasher((0, 0)) as h2:
+        assert h2.device_count == 2
+        h2.set_option("host_threshold_bytes", 0)
+        assert_same(h2.hash_blobs(blobs), want, lens)
+        assert h2.stat("launches") >= 2
+
+
+def test_config2_full_size_1m_x_4k(hasher):
+    """BASELINE configs[1] at full size: 1,000,000 x 4 KiB blobs generated on the
+    device; every digest checked against hashlib (OpenSSL) on the host copy of the
+    same bytes, on 16 threads; both kernels must agree bit for bit."""
+    import vit_amd
+    n, L = 1_000_000, 4096
+    hasher.set_option("kernel", 0)
+    b = hasher.synth_arena("blob", 0x5EED0002, 0, n, L)
+    d_lds = hasher.hash_device(b).copy()
+    hasher.set_option("kernel", 1)
+    d_lane = hasher.hash_device(b).copy()
+    hasher.set_option("kernel", 0)
+    assert hasher.device_status() == 0
+    assert (d_lds == d_lane).all()
+    slot = vit_amd.object_blocks("blob", L) * 64
+    hl = vit_amd.header_len("blob", L)
+    # generator spot check against the host restatement of the byte stream
+    for i in (0, 1, 999_999):
+        raw = b["arena"].download(np.uint8, slot, offset=i * slot).tobytes()
+        assert raw[:hl] == b"blob 4096\0" and raw[hl:hl + L] == vit_amd.synth_bytes(0x5EED0002, i, L)
+
+    mv = memoryview(b["arena"].download(np.uint8, n * slot))     # one 4.16 GB copy, main thread
+
+    def check(lo, hi):
+        for i in range(lo, hi):
+            base = i * slot
+            if hashlib.sha1(mv[base:base + hl + L]).digest() != d_lds[i].tobytes():
+                return i
+        return -1
+    step = 12500
+    with concurrent.futures.ThreadPoolExecutor(16) as ex:
+        bad = [r for r in ex.map(lambda lo: check(lo, min(lo + step, n)), range(0, n, step)) if r >= 0]
+    assert not bad, "first differing blob: %d" % bad[0]
+    # order-independent summary of all ids, for the record
+    acc = np.bitwise_xor.reduce(d_lds, axis=0)
+    assert acc.shape == (20,)

@@ -457,6 +457,18 @@ int vit_host_object_id(const char* type, const uint8_t* data, uint64_t len, uint
     return VIT_OK;
 }
 
+int vit_shard_plan(const uint32_t* nblocks, uint64_t n, int n_queues, uint32_t* queue_of)
+{
+    if (n_queues < 1 || (n && (!nblocks || !queue_of))) return VIT_ERR_ARG;
+    std::vector<uint64_t> idx(n);
+    for (uint64_t i = 0; i < n; ++i) idx[i] = i;
+    std::vector<std::vector<uint64_t>> parts;
+    shard(idx, nblocks, size_t(n_queues), parts);
+    for (size_t q = 0; q < parts.size(); ++q)
+        for (uint64_t i : parts[q]) queue_of[i] = uint32_t(q);
+    return VIT_OK;
+}
+
 int vit_arena_alloc(vit_hasher* h, uint64_t bytes, void** out)
 {
     if (!h || !out) return VIT_ERR_ARG;
