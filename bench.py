@@ -41,6 +41,9 @@ def parse():
     ap.add_argument("--kernel", choices=["lds", "lane"], default="lds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget for the baseline leg")
+    ap.add_argument("--dist-backend", default=None,
+                    help="torch.distributed backend for the timing barrier (default: nccl = RCCL; gloo lets two "
+                         "ranks rehearse on one GPU)")
     ap.add_argument("--end-to-end", action="store_true", help="also time pack + H2D + kernel + D2H from host memory")
     return ap.parse_args()
 
@@ -105,25 +108,18 @@ def cpu_baseline(args, gpu_digests_of_sample):
 
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-
     import torch
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
     import vit_amd
+    from vit_amd import dist as vdist
+    rank, local_rank, world = vdist.env()
+    dist = vdist.init(args.dist_backend)   # RCCL ("nccl") process group when WORLD_SIZE > 1; carries timing only
+
     dev_id = local_rank if torch.cuda.device_count() > local_rank else 0
     h = vit_amd.Hasher((dev_id,))
     h.set_option("kernel", vit_amd.KERNEL_LDS if args.kernel == "lds" else vit_amd.KERNEL_LANE)
 
     n, L = args.blobs, args.blob_len
-    batch = h.synth_arena("blob", SEED, rank * n, n, L)          # rank r hashes blobs [r*n, (r+1)*n)
+    batch = h.synth_arena("blob", SEED, vdist.weak_first_index(rank, n), n, L)   # rank r: blobs [r*n, (r+1)*n)
     hdr = vit_amd.header_len("blob", L)
     nb = vit_amd.object_blocks("blob", L)
 
@@ -143,12 +139,10 @@ def main():
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    elapsed = vdist.max_over_ranks(dist, elapsed)
+    status = vdist.sum_over_ranks(dist, h.device_status(0))
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         dist.barrier()
-    status = h.device_status(0)
 
     if rank != 0:
         if dist is not None:

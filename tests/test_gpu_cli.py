@@ -1,0 +1,165 @@
+"""The C++ object store and the `vit` front end (vit_amd/bin/vit) on a GPU:
+same stdout, ids, stored objects and failure behaviour as the reference's
+hash-object / write-tree / commit-tree (src/main.cpp:90-186, src/commit.cpp:88-173)."""
+import hashlib
+import os
+import shutil
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VIT = os.path.join(ROOT, "vit_amd", "bin", "vit")
+
+
+def vit(cwd, *args, env=None, check=True):
+    e = dict(os.environ)
+    e.setdefault("VIT_DEVICES", "0")
+    if env:
+        e.update(env)
+    p = subprocess.run([VIT] + list(args), cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=240)
+    if check:
+        assert p.returncode == 0, p.stderr.decode()
+    return p
+
+
+def stored_objects(wt):
+    out = {}
+    base = os.path.join(wt, ".git", "objects")
+    for d in os.listdir(base):
+        for f in os.listdir(os.path.join(base, d)):
+            raw = zlib.decompress(open(os.path.join(base, d, f), "rb").read())
+            assert hashlib.sha1(raw).hexdigest() == d + f, "object file name is not the SHA-1 of its content"
+            out[d + f] = raw
+    return out
+
+
+def fresh_copy(src, dst):
+    shutil.copytree(src, dst, symlinks=True)
+    vit(dst, "init")
+    return str(dst)
+
+
+def test_binary_exists():
+    assert os.path.exists(VIT), "build vit_amd/bin/vit with `python -m vit_amd.build`"
+
+
+def test_write_tree_matches_reference_on_every_golden_worktree(golden_trees, worktrees, tmp_path):
+    for name, rec in golden_trees.items():
+        wt = fresh_copy(worktrees[name], tmp_path / name)
+        p = vit(wt, "write-tree")
+        assert p.stdout.decode() == rec["root"] + "\n", name
+        objs = stored_objects(wt)
+        assert set(rec["tree_ids"]) <= set(objs), name
+        assert set(rec["blob_ids"]) <= set(objs), name
+        assert sum(1 for v in objs.values() if v.startswith(b"blob ")) == rec["n_blobs"], name
+        # a second run rewrites the same objects and prints the same id (the reference always rewrites, :110)
+        assert vit(wt, "write-tree").stdout.decode() == rec["root"] + "\n"
+
+
+def test_stored_objects_are_byte_identical_to_the_oracles(oracle, golden_trees, worktrees, tmp_path):
+    """Same zlib, same level, same framing => the loose-object files themselves match
+    what the reference's writeObject stores (src/commit.cpp:98-111)."""
+    wt = fresh_copy(worktrees["nested_names"], tmp_path / "wt")
+    vit(wt, "write-tree")
+    ref_dir = tmp_path / "oracle_objects"
+    oracle.write_tree(worktrees["nested_names"], str(ref_dir))
+    n = 0
+    for d in os.listdir(ref_dir):
+        for f in os.listdir(ref_dir / d):
+            mine = os.path.join(wt, ".git", "objects", d, f)
+            assert open(mine, "rb").read() == open(ref_dir / d / f, "rb").read(), d + f
+            n += 1
+    assert n >= len(golden_trees["nested_names"]["tree_ids"]) + len(golden_trees["nested_names"]["blob_ids"])
+
+
+def test_git_reads_what_write_tree_stored(golden_trees, worktrees, tmp_path):
+    if not shutil.which("git"):
+        pytest.skip("no git here")
+    wt = fresh_copy(worktrees["c1_1000x4096"], tmp_path / "c1")
+    root = vit(wt, "write-tree").stdout.decode().strip()
+    assert root == golden_trees["c1_1000x4096"]["git_write_tree"]       # on this worktree reference == git
+    out = subprocess.check_output(["git", "-C", wt, "ls-tree", root]).decode().splitlines()
+    assert len(out) == 10 and all(l.startswith("040000 tree ") for l in out)
+    some_blob = golden_trees["c1_1000x4096"]["blob_ids"][123]
+    assert subprocess.check_output(["git", "-C", wt, "cat-file", "-t", some_blob]).decode().strip() == "blob"
+
+
+def test_hash_object_prints_the_reference_ids(oracle, golden_objects, tmp_path):
+    wt = tmp_path / "ho"
+    wt.mkdir()
+    vit(str(wt), "init")
+    g = golden_objects["blobs"]
+    for L, want in g["ids"][::9] + [g["ids"][0]]:
+        (wt / "f.bin").write_bytes(oracle.synth_bytes(g["seed"], L, L))
+        assert vit(str(wt), "hash-object", "-w", "f.bin").stdout.decode() == want + "\n", L
+        assert vit(str(wt), "cat-file", "-p", want, check=(L > 0)).stdout == oracle.synth_bytes(g["seed"], L, L)
+    p = vit(str(wt), "hash-object", "-w", "missing", check=False)
+    assert p.returncode == 1 and b"Failed to open file" in p.stderr
+    assert vit(str(wt), "hash-object", "f.bin", check=False).returncode == 1
+
+
+def test_commit_tree_with_pinned_clock(oracle, tmp_path):
+    wt = tmp_path / "ct"
+    wt.mkdir()
+    vit(str(wt), "init")
+    (wt / ".vitconfig").write_text("1\nalice\nalice@example.org\n")
+    tree = "4b825dc642cb6eb9a060e54bf8d69288fbee4904"
+    parent = "ce013625030ba8dba906f756967f9e9ca394464a"
+    got = vit(str(wt), "commit-tree", tree, "-p", parent, "-m", "first", env={"VIT_COMMIT_TIME": "1700000000"}).stdout.decode().strip()
+    text = oracle.commit_text(tree, parent, "first", "alice", "alice@example.org", 1700000000, 1700000000)
+    assert got == oracle.object_id("commit", text).hex()
+    assert vit(str(wt), "cat-file", "-p", got).stdout == text
+
+
+def test_ls_tree_lists_sorted_entries(golden_trees, worktrees, tmp_path):
+    wt = fresh_copy(worktrees["dir_vs_file_prefix"], tmp_path / "ls")
+    root = vit(wt, "write-tree").stdout.decode().strip()
+    names = vit(wt, "ls-tree", root, "--name-only").stdout.decode().split()
+    assert names == ["foo", "foo-bar", "foo.c"]          # the reference's plain-name order (src/commit.cpp:164-165)
+    long = vit(wt, "ls-tree", root, "-l").stdout.decode().splitlines()
+    assert long[0].startswith("40000 tree ") and long[1].startswith("100644 blob ")
+
+
+def test_write_tree_fails_like_the_reference_on_special_files(tmp_path):
+    wt = tmp_path / "bad"
+    (wt / "sub").mkdir(parents=True)
+    (wt / "sub" / "ok.txt").write_text("x")
+    os.mkfifo(wt / "sub" / "pipe")                       # neither regular file nor directory (src/commit.cpp:160)
+    vit(str(wt), "init")
+    p = vit(str(wt), "write-tree", check=False)
+    assert p.returncode == 1 and p.stdout == b"" and b"Failed to write tree" in p.stderr
+
+
+def test_symlinks_are_followed_and_dot_git_skipped_at_every_level(oracle, tmp_path):
+    wt = tmp_path / "sl"
+    (wt / "real").mkdir(parents=True)
+    (wt / "real" / "a").write_bytes(b"A" * 100)
+    (wt / "real" / ".git").mkdir()                       # a nested directory literally named .git is skipped (:145)
+    (wt / "real" / ".git" / "junk").write_text("junk")
+    os.symlink("real", wt / "link")                      # followed: hashed as a second copy of the directory
+    os.symlink("real/a", wt / "alink")
+    vit(str(wt), "init")
+    got = vit(str(wt), "write-tree").stdout.decode().strip()
+    assert got == oracle.write_tree(str(wt))[0].hex()
+
+
+def test_medium_worktree_skewed_sizes(oracle, tmp_path):
+    """~6,000 files with a heavy small-file skew and a few MiB-sized ones, 3 levels deep."""
+    rng = np.random.default_rng(3)
+    wt = tmp_path / "skew"
+    sizes = np.minimum((np.exp(rng.normal(np.log(4500), 1.55, 6000))).astype(np.int64), 4 << 20)
+    sizes[:3] = [0, 3 << 20, 1]
+    for i, L in enumerate(sizes):
+        d = wt / ("m%02d" % (i % 37)) / ("s%d" % (i % 5))
+        d.mkdir(parents=True, exist_ok=True)
+        (d / ("f%05d.dat" % i)).write_bytes(oracle.synth_bytes(0x5EED0003, i, int(L)))
+    vit(str(wt), "init")
+    p = vit(str(wt), "write-tree", "--stats")
+    want, n_blobs, n_trees = oracle.write_tree(str(wt))
+    assert p.stdout.decode().strip() == want.hex()
+    assert ("blobs %d trees %d" % (n_blobs, n_trees)).encode() in p.stderr

@@ -1,0 +1,105 @@
+// object_store.hpp — the reference's object-store interface over the batched
+// GPU hasher.
+//
+// The free functions at the bottom carry the reference's names, signatures and
+// conventions (reference src/commit.hpp:8-18): ids are 40 lowercase hex
+// characters, failure is the empty string with a message on std::cerr, objects
+// go to the CWD-relative ".git/objects/aa/bbbb…" as zlib streams of
+// "<type> <len>\0" + content.  What differs is where the SHA-1 runs (one GPU
+// batch through include/vit_hash.h instead of one OpenSSL call per object) and
+// that writeTree walks first, hashes every blob of the worktree in one batch,
+// then assembles the trees bottom-up, one batch per depth level, while a host
+// thread pool deflates and stores the objects.
+#pragma once
+#include <cstdint>
+#include <ctime>
+#include <functional>
+#include <string>
+#include <vector>
+
+struct vit_hasher;
+
+/* ---------- data structures (reference src/commit.hpp:31-35) ---------- */
+struct TreeEntry {
+    std::string mode;
+    std::string hash;
+    std::string filename;
+};
+
+namespace vit {
+
+struct StoreStats {
+    uint64_t blobs = 0, trees = 0, bytes = 0;
+    double walk_s = 0, read_s = 0, hash_s = 0, deflate_store_s = 0, total_s = 0;
+};
+
+class ObjectStore {
+public:
+    // objects_dir: where loose objects go (reference: ".git/objects", src/commit.cpp:83,108).
+    // devices: HIP ordinals for the hasher (empty = every visible GPU).
+    explicit ObjectStore(std::string objects_dir = ".git/objects", std::vector<int> devices = {});
+    ~ObjectStore();
+    ObjectStore(const ObjectStore&) = delete;
+    ObjectStore& operator=(const ObjectStore&) = delete;
+
+    // false (with the reason on std::cerr) when no GPU hasher could be created.
+    bool ok() const { return hasher_ != nullptr; }
+
+    // reference src/commit.cpp:88-114 / :116
+    std::string writeObject(const std::string& type, const std::string& content);
+    std::string writeBlob(const std::string& content) { return writeObject("blob", content); }
+    // Many objects of one type in one GPU batch; ids in input order, {} on failure.
+    std::vector<std::string> writeObjects(const std::string& type, const std::vector<std::string>& contents);
+
+    // reference src/commit.cpp:139-173, batched (same ids, same stored objects).
+    std::string writeTree(const std::string& directoryPath);
+
+    // reference src/commit.cpp:263-276; `now` replaces its two time(nullptr) calls.
+    std::string writeCommit(const std::string& treeHash, const std::string& parentHash, const std::string& message,
+                            const std::string& author, const std::string& email, std::time_t now = std::time(nullptr));
+
+    // reference src/commit.cpp:120-136
+    std::string readObject(const std::string& hash) const;
+    std::string readObjectContent(const std::string& hash) const;
+
+    // Hash without storing (ids only); raw 20-byte digests appended to out.
+    bool hashObjects(const std::string& type, const std::vector<const std::string*>& contents, std::vector<uint8_t>& out);
+
+    void setStoreObjects(bool on) { store_ = on; }          // false: compute ids only (benchmarks)
+    void setIoThreads(int n) { io_threads_ = n < 1 ? 1 : n; }
+    void setBatchBytes(uint64_t b) { batch_bytes_ = b; }
+    const StoreStats& lastStats() const { return stats_; }
+    vit_hasher* hasher() const { return hasher_; }
+    std::string objectPath(const std::string& hash) const;
+
+private:
+    bool storeFramed(const std::string& hex, const std::string& type, const std::string& content) const;
+    std::string objects_dir_;
+    vit_hasher* hasher_ = nullptr;
+    bool store_ = true;
+    int io_threads_ = 8;
+    uint64_t batch_bytes_ = 1ull << 30;
+    StoreStats stats_;
+};
+
+// The store behind the free functions below: ".git/objects" relative to the
+// current directory, devices from $VIT_DEVICES ("0,1,…"; unset = all).
+ObjectStore& defaultStore();
+
+}  // namespace vit
+
+/* ---------- Low-level object helpers (reference src/commit.hpp:8-18) ---------- */
+std::string hashToHexString(const unsigned char* hash);
+std::string hexStringToBinary(const std::string& hexString);
+std::string binaryToHexString(const std::string& binary);
+std::string getObjectPath(const std::string& hash);
+
+std::string writeObject(const std::string& type, const std::string& content);
+std::string writeBlob(const std::string& content);
+std::string writeTree(const std::string& directoryPath);
+
+std::string readObject(const std::string& hash);
+std::string readObjectContent(const std::string& hash);
+
+std::string writeCommit(const std::string& treeHash, const std::string& parentHash, const std::string& message,
+                        const std::string& author, const std::string& email);

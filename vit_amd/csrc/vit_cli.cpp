@@ -1,0 +1,149 @@
+// vit_cli.cpp — the plumbing commands of the reference that sit on the
+// content-addressing path, on top of the GPU-backed object store:
+//
+//   vit init
+//   vit hash-object -w <file>            reference src/main.cpp:90-120
+//   vit write-tree [--stats] [--no-store] reference src/main.cpp:155-163
+//   vit commit-tree <tree> -p <parent> -m <message>   reference src/main.cpp:165-186
+//   vit cat-file -p <hash>               reference src/main.cpp:68-88
+//   vit ls-tree <hash> --name-only|-l    reference src/main.cpp:122-153
+//
+// stdout carries exactly what the reference prints (the id and a newline);
+// the exit status is 0 on success, 1 on failure.  Author name and e-mail come
+// from the reference's ".vitconfig" (three whitespace separated fields,
+// src/main.cpp:35-41) or $VIT_AUTHOR / $VIT_EMAIL; $VIT_COMMIT_TIME pins the
+// clock for reproducible commits; $VIT_DEVICES picks the GPUs.
+#include "object_store.hpp"
+
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+namespace {
+
+struct Config { bool localAI = true; std::string userName, userEmail; };
+
+Config loadConfig()
+{
+    Config c;
+    std::ifstream f(".vitconfig");
+    if (f) { f >> c.localAI; f >> c.userName; f >> c.userEmail; }
+    if (const char* e = std::getenv("VIT_AUTHOR")) c.userName = e;
+    if (const char* e = std::getenv("VIT_EMAIL")) c.userEmail = e;
+    return c;
+}
+
+bool cmdInit()
+{
+    std::error_code ec;
+    for (const char* d : {".git", ".git/objects", ".git/refs", ".git/refs/heads"}) {
+        std::filesystem::create_directory(d, ec);
+        if (ec) { std::cerr << ec.message() << '\n'; return false; }
+    }
+    std::ofstream head(".git/HEAD");
+    if (!head) { std::cerr << "Failed to create .git/HEAD file.\n"; return false; }
+    head << "ref: refs/heads/main\n";
+    std::cout << "Initialized vit directory\n";
+    return true;
+}
+
+bool cmdHashObject(int argc, char** argv)
+{
+    if (argc < 4) { std::cerr << "Usage: hash-object -w <file>\n"; return false; }
+    if (std::string(argv[2]) != "-w") { std::cerr << "Unknown flag: " << argv[2] << '\n'; return false; }
+    std::ifstream in(argv[3], std::ios::binary);
+    if (!in.is_open()) { std::cerr << "Failed to open file: " << argv[3] << '\n'; return false; }
+    std::stringstream ss;
+    ss << in.rdbuf();
+    const std::string id = writeBlob(ss.str());
+    if (id.empty()) return false;
+    std::cout << id << '\n';
+    return true;
+}
+
+bool cmdWriteTree(int argc, char** argv)
+{
+    bool stats = false;
+    for (int i = 2; i < argc; ++i) {
+        if (!std::strcmp(argv[i], "--stats")) stats = true;
+        else if (!std::strcmp(argv[i], "--no-store")) vit::defaultStore().setStoreObjects(false);
+        else { std::cerr << "Unknown flag: " << argv[i] << '\n'; return false; }
+    }
+    const std::string id = writeTree(".");
+    if (id.empty()) { std::cerr << "Failed to write tree\n"; return false; }
+    std::cout << id << '\n';
+    if (stats) {
+        const vit::StoreStats& s = vit::defaultStore().lastStats();
+        std::cerr << "blobs " << s.blobs << " trees " << s.trees << " bytes " << s.bytes << " | walk " << s.walk_s
+                  << " s read " << s.read_s << " s hash " << s.hash_s << " s hash+deflate+store " << s.deflate_store_s
+                  << " s total " << s.total_s << " s\n";
+    }
+    return true;
+}
+
+bool cmdCommitTree(int argc, char** argv)
+{
+    if (argc < 7) { std::cerr << "Usage: commit-tree <tree_sha> -p <commit_sha> -m <message>\n"; return false; }
+    const Config cfg = loadConfig();
+    std::time_t now = std::time(nullptr);
+    if (const char* e = std::getenv("VIT_COMMIT_TIME")) now = std::time_t(std::atoll(e));
+    const std::string id = vit::defaultStore().writeCommit(argv[2], argv[4], argv[6], cfg.userName, cfg.userEmail, now);
+    if (id.empty()) { std::cerr << "Failed to create commit\n"; return false; }
+    std::cout << id << '\n';
+    return true;
+}
+
+bool cmdCatFile(int argc, char** argv)
+{
+    if (argc < 4) { std::cerr << "Usage: cat-file -p <hash>\n"; return false; }
+    if (std::string(argv[2]) != "-p") { std::cerr << "Unknown flag: " << argv[2] << '\n'; return false; }
+    const std::string content = readObjectContent(argv[3]);
+    if (content.empty()) return false;
+    std::cout << content;
+    return true;
+}
+
+bool cmdLsTree(int argc, char** argv)
+{
+    if (argc < 4) { std::cerr << "Usage: ls-tree <hash> [--name-only|-l]\n"; return false; }
+    const std::string flag = argv[3];
+    if (flag != "--name-only" && flag != "-l") { std::cerr << "Unknown flag: " << flag << '\n'; return false; }
+    const std::string content = readObjectContent(argv[2]);
+    if (content.empty()) { std::cerr << "Tree not found or empty: " << argv[2] << '\n'; return false; }
+    for (size_t pos = 0; pos < content.size();) {
+        const size_t nul = content.find('\0', pos);
+        if (nul == std::string::npos || nul + 21 > content.size()) break;
+        const std::string head = content.substr(pos, nul - pos);
+        const size_t sp = head.find_last_of(' ');
+        if (sp != std::string::npos) {
+            const std::string mode = head.substr(0, sp), name = head.substr(sp + 1);
+            if (flag == "--name-only") std::cout << name << '\n';
+            else std::cout << mode << ' ' << (mode.rfind("400", 0) == 0 ? "tree" : "blob") << ' '
+                           << binaryToHexString(content.substr(nul + 1, 20)) << '\t' << name << '\n';
+        }
+        pos = nul + 21;
+    }
+    return true;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    std::cout << std::unitbuf;
+    std::cerr << std::unitbuf;
+    if (argc < 2) { std::cerr << "No command provided.\n"; return EXIT_FAILURE; }
+    const std::string cmd = argv[1];
+    bool ok;
+    if (cmd == "init") ok = cmdInit();
+    else if (cmd == "hash-object") ok = cmdHashObject(argc, argv);
+    else if (cmd == "write-tree") ok = cmdWriteTree(argc, argv);
+    else if (cmd == "commit-tree") ok = cmdCommitTree(argc, argv);
+    else if (cmd == "cat-file") ok = cmdCatFile(argc, argv);
+    else if (cmd == "ls-tree") ok = cmdLsTree(argc, argv);
+    else { std::cerr << "Unknown command " << cmd << '\n'; return EXIT_FAILURE; }
+    return ok ? EXIT_SUCCESS : EXIT_FAILURE;
+}
