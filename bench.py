@@ -193,12 +193,16 @@ def main():
         m = min(n, 262144)
         host = O.synth_fill_many(SEED, 0, m, L, threads=8)
         blobs = [host[i * L:(i + 1) * L] for i in range(m)]
-        h.hash_blobs(blobs[:1024])
-        t0 = time.perf_counter()
-        got = h.hash_blobs(blobs)
-        dt = time.perf_counter() - t0
-        line["end_to_end_host_memory"] = {"value": round(m * L / dt / 1e9, 3), "unit": "GB/s", "blobs": m,
-                                          "pack_ms": round(h.stat("last_pack_ns") / 1e6, 2),
+        h.hash_blobs(blobs)                               # first call sizes the pinned and device staging buffers
+        runs = []
+        for _ in range(3):
+            got = h.hash_blobs(blobs)
+            runs.append((h.stat("last_total_ns"), h.stat("last_pack_ns")))
+        total_ns, pack_ns = sorted(runs)[1]
+        # time inside vit_hash_blobs (pack + H2D + kernel + D2H), without the Python argument marshalling
+        line["end_to_end_host_memory"] = {"value": round(m * L / total_ns, 3), "unit": "GB/s", "blobs": m,
+                                          "total_ms": round(total_ns / 1e6, 2), "pack_ms": round(pack_ns / 1e6, 2),
+                                          "pack_threads": min(os.cpu_count() or 1, 16),
                                           "matches": bool((got == dig[:m]).all())}
     print(json.dumps(line), flush=True)
     if dist is not None:
