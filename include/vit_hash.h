@@ -60,15 +60,24 @@ const char *vit_last_error(const vit_hasher *h);
 
 int vit_hasher_device_count(const vit_hasher *h);
 
-/* Options: "kernel" (VIT_KERNEL_*), "host_threshold_bytes" (objects larger than
- * this are hashed on host threads while the GPU batch runs, because one SHA-1
- * stream is serial and a single lane is slower than a host core; 0 = never,
- * the default is 16 MiB), "chunk_bytes" (pinned staging buffer size per queue),
- * "pack_threads". */
+/* Options:
+ *  "kernel"               VIT_KERNEL_*
+ *  "host_threshold_bytes" objects larger than this are hashed on host threads
+ *                         while the GPU batch runs (one SHA-1 stream is serial;
+ *                         a lane sustains ~50 MB/s, a host core ~2 GB/s);
+ *                         0 = never, every object takes a GPU lane
+ *  "host_auto"            1 (default): derive that threshold per call as
+ *                         clamp(batch bytes per queue / 1024, 64 KiB, 16 MiB),
+ *                         i.e. keep an object on the GPU when its lane time
+ *                         hides inside the batch's transfer time
+ *  "chunk_bytes"          pinned staging buffer size per queue and stream
+ *  "pack_threads"         host threads for packing and for the host lane */
 int vit_hasher_set_option(vit_hasher *h, const char *name, uint64_t value);
 
-/* Counters since creation: "objects_gpu", "objects_host", "blocks_gpu",
- * "bytes_h2d", "launches", "last_kernel_ns", "last_pack_ns", "last_total_ns". */
+/* Counters since creation: "objects_gpu", "objects_host", "bytes_host",
+ * "blocks_gpu", "bytes_h2d", "launches"; of the last call: "last_kernel_ns",
+ * "last_pack_ns", "last_total_ns", "last_host_threshold"; and
+ * "host_sha_accelerated" (1 when the host lane uses the CPU's SHA extensions). */
 int vit_hasher_get_stat(const vit_hasher *h, const char *name, uint64_t *value);
 
 /* ---- framing (reference src/commit.cpp:90) ------------------------------- */

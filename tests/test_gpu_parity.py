@@ -87,7 +87,12 @@ def test_skewed_batch_with_large_objects(hasher, oracle, kernel):
     g0, h0 = hasher.stat("objects_gpu"), hasher.stat("objects_host")
     assert_same(hasher.hash_blobs(blobs), want, lens)
     assert hasher.stat("objects_host") - h0 == 2 and hasher.stat("objects_gpu") - g0 == len(lens) - 2
-    hasher.set_option("host_threshold_bytes", 16 << 20)
+    hasher.set_option("host_auto", 1)
+    # auto policy: a small batch keeps everything up to 64 KiB on the lanes, sends the MiB-sized ones to the host
+    g0, h0 = hasher.stat("objects_gpu"), hasher.stat("objects_host")
+    assert_same(hasher.hash_blobs(blobs), want, lens)
+    assert hasher.stat("last_host_threshold") == 64 << 10
+    assert hasher.stat("objects_host") - h0 == 3
 
 
 def test_chunked_pipeline_matches_single_chunk(hasher, oracle):

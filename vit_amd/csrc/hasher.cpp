@@ -51,10 +51,10 @@ struct Staging {
 
 struct Queue {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream[3] = {nullptr, nullptr, nullptr};   // [0],[1]: alternating chunks; [2]: long objects
     uint32_t* d_status = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
-    Staging st[2];
+    Staging st[3];
     std::string err;                                      // set by the queue's worker thread
 };
 
@@ -64,10 +64,14 @@ struct vit_hasher {
     std::vector<Queue> queues;
     mutable std::string err;
     int kernel = VIT_KERNEL_LDS;
-    uint64_t host_threshold = 16ull << 20;
-    uint64_t chunk_bytes = 256ull << 20;
+    // Which objects go to host threads instead of a GPU lane: 0 never, 1 auto
+    // (threshold derived from the batch, see vit_hash_objects), 2 fixed threshold.
+    int host_policy = 1;
+    uint64_t host_threshold = 0;
+    uint64_t chunk_bytes = 64ull << 20;
     int pack_threads = 8;
-    std::atomic<uint64_t> objects_gpu{0}, objects_host{0}, blocks_gpu{0}, bytes_h2d{0}, launches{0};
+    std::atomic<uint64_t> objects_gpu{0}, objects_host{0}, bytes_host{0}, blocks_gpu{0}, bytes_h2d{0}, launches{0};
+    uint64_t last_host_threshold = 0;
     uint64_t last_kernel_ns = 0, last_pack_ns = 0, last_total_ns = 0;
 };
 
@@ -189,66 +193,100 @@ struct Job {
     uint8_t* digests;
 };
 
+// Pack one chunk (objects idx[0..cnt)) into staging set s and queue its copy,
+// kernel and digest read-back on `stream`.
+int submit_chunk(Queue& q, const Job& job, Staging& s, hipStream_t stream, const uint64_t* idx, uint64_t cnt,
+                 uint64_t* pack_ns)
+{
+    vit_hasher* h = job.h;
+    int rc = retire(q, s, job.digests);
+    if (rc) return rc;
+    uint64_t blocks = 0;
+    for (uint64_t i = 0; i < cnt; ++i) blocks += job.nb[idx[i]];
+    const uint64_t bytes = blocks * 64;
+    if ((rc = ensure_arena(q, s, bytes))) return rc;
+    if ((rc = ensure_meta(q, s, cnt))) return rc;
+
+    const auto t0 = clk::now();
+    s.obj.assign(idx, idx + cnt);
+    std::vector<uint64_t> prefix(cnt + 1, 0);
+    for (uint64_t i = 0; i < cnt; ++i) {
+        s.h_off[i] = prefix[i] * 64;
+        s.h_nb[i] = job.nb[idx[i]];
+        prefix[i + 1] = prefix[i] + s.h_nb[i];
+    }
+    const int threads = bytes < (4u << 20) ? 1 : h->pack_threads;
+    vit::parallel_ranges(cnt, threads, prefix.data(), [&](int, uint64_t b, uint64_t e) {
+        for (uint64_t i = b; i < e; ++i) {
+            const uint64_t o = idx[i];
+            vit::pack_one(job.type, job.tl, job.data[o], job.len[o], s.h_arena + s.h_off[i], s.h_nb[i]);
+        }
+    });
+    const bool binned = vit::bin_order(s.h_nb, cnt, s.h_order);
+    *pack_ns += ns_since(t0);
+
+    HIP_TRYQ(q, hipMemcpyAsync(s.d_arena, s.h_arena, bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRYQ(q, hipMemcpyAsync(s.d_off, s.h_off, cnt * 8, hipMemcpyHostToDevice, stream));
+    HIP_TRYQ(q, hipMemcpyAsync(s.d_nb, s.h_nb, cnt * 4, hipMemcpyHostToDevice, stream));
+    if (binned) HIP_TRYQ(q, hipMemcpyAsync(s.d_order, s.h_order, cnt * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRYQ(q, vit::launch_sha1(vit::KernelVariant(h->kernel),
+                                 make_batch(q, s.d_arena, bytes, s.d_off, s.d_nb, binned ? s.d_order : nullptr, cnt,
+                                            s.d_dig),
+                                 stream));
+    HIP_TRYQ(q, hipMemcpyAsync(s.h_dig, s.d_dig, cnt * 20, hipMemcpyDeviceToHost, stream));
+    HIP_TRYQ(q, hipEventRecord(s.done, stream));
+    s.in_flight = true;
+    h->objects_gpu += cnt; h->blocks_gpu += blocks; h->bytes_h2d += bytes + cnt * 16; ++h->launches;
+    return VIT_OK;
+}
+
+// Objects of at least this many blocks (256 KiB) are "long": a lane hashes about
+// 50 MB/s, so each of them holds its wave for milliseconds.  They are launched
+// first, on a stream and staging set of their own, and the short objects'
+// chunks stream past them on the other two.
+constexpr uint32_t kLongBlocks = 4096;
+
 // Hash the objects `mine` (caller indices, in order) on queue q.
 int run_queue(Queue& q, const Job& job, const std::vector<uint64_t>& mine, uint64_t* pack_ns)
 {
     vit_hasher* h = job.h;
     HIP_TRYQ(q, hipSetDevice(q.device));
-    size_t pos = 0;
+    std::vector<uint64_t> longs, rest;
+    for (uint64_t i : mine) (job.nb[i] >= kLongBlocks ? longs : rest).push_back(i);
+    std::stable_sort(longs.begin(), longs.end(), [&](uint64_t a, uint64_t b) { return job.nb[a] > job.nb[b]; });
+
+    // Chunk boundaries: as many objects as fit the staging budget (at least one).
+    auto cut = [&](const std::vector<uint64_t>& v, uint64_t budget) {
+        std::vector<std::pair<size_t, size_t>> out;
+        for (size_t pos = 0; pos < v.size();) {
+            uint64_t blocks = 0;
+            size_t end = pos;
+            while (end < v.size() && (end == pos || (blocks + job.nb[v[end]]) * 64 <= budget)) blocks += job.nb[v[end++]];
+            out.emplace_back(pos, end);
+            pos = end;
+        }
+        return out;
+    };
+    const auto long_chunks = cut(longs, h->chunk_bytes * 4);
+    const auto rest_chunks = cut(rest, h->chunk_bytes);
+
+    int rc;
+    if (!long_chunks.empty() &&
+        (rc = submit_chunk(q, job, q.st[2], q.stream[2], longs.data() + long_chunks[0].first,
+                           long_chunks[0].second - long_chunks[0].first, pack_ns)))
+        return rc;
     int turn = 0;
-    while (pos < mine.size()) {
-        // Chunk: as many objects as fit the staging budget (at least one).
-        uint64_t blocks = 0;
-        size_t end = pos;
-        while (end < mine.size()) {
-            const uint64_t nb = job.nb[mine[end]];
-            if (end > pos && (blocks + nb) * 64 > h->chunk_bytes) break;
-            blocks += nb; ++end;
-        }
-        const uint64_t cnt = end - pos, bytes = blocks * 64;
-        Staging& s = q.st[turn];
+    for (const auto& c : rest_chunks) {
+        if ((rc = submit_chunk(q, job, q.st[turn], q.stream[turn], rest.data() + c.first, c.second - c.first, pack_ns)))
+            return rc;
         turn ^= 1;
-        int rc = retire(q, s, job.digests);
-        if (rc) return rc;
-        if ((rc = ensure_arena(q, s, bytes))) return rc;
-        if ((rc = ensure_meta(q, s, cnt))) return rc;
-
-        const auto t0 = clk::now();
-        s.obj.assign(mine.begin() + long(pos), mine.begin() + long(end));
-        std::vector<uint64_t> prefix(cnt + 1, 0);
-        for (uint64_t i = 0; i < cnt; ++i) {
-            s.h_off[i] = prefix[i] * 64;
-            s.h_nb[i] = job.nb[s.obj[i]];
-            prefix[i + 1] = prefix[i] + s.h_nb[i];
-        }
-        const int threads = bytes < (8u << 20) ? 1 : h->pack_threads;
-        vit::parallel_ranges(cnt, threads, prefix.data(), [&](int, uint64_t b, uint64_t e) {
-            for (uint64_t i = b; i < e; ++i) {
-                const uint64_t o = s.obj[i];
-                vit::pack_one(job.type, job.tl, job.data[o], job.len[o], s.h_arena + s.h_off[i], s.h_nb[i]);
-            }
-        });
-        const bool binned = vit::bin_order(s.h_nb, cnt, s.h_order);
-        *pack_ns += ns_since(t0);
-
-        HIP_TRYQ(q, hipMemcpyAsync(s.d_arena, s.h_arena, bytes, hipMemcpyHostToDevice, q.stream));
-        HIP_TRYQ(q, hipMemcpyAsync(s.d_off, s.h_off, cnt * 8, hipMemcpyHostToDevice, q.stream));
-        HIP_TRYQ(q, hipMemcpyAsync(s.d_nb, s.h_nb, cnt * 4, hipMemcpyHostToDevice, q.stream));
-        if (binned) HIP_TRYQ(q, hipMemcpyAsync(s.d_order, s.h_order, cnt * 4, hipMemcpyHostToDevice, q.stream));
-        HIP_TRYQ(q, vit::launch_sha1(vit::KernelVariant(h->kernel),
-                                     make_batch(q, s.d_arena, bytes, s.d_off, s.d_nb, binned ? s.d_order : nullptr,
-                                                cnt, s.d_dig),
-                                     q.stream));
-        HIP_TRYQ(q, hipMemcpyAsync(s.h_dig, s.d_dig, cnt * 20, hipMemcpyDeviceToHost, q.stream));
-        HIP_TRYQ(q, hipEventRecord(s.done, q.stream));
-        s.in_flight = true;
-        h->objects_gpu += cnt; h->blocks_gpu += blocks; h->bytes_h2d += bytes + cnt * 16; ++h->launches;
-        pos = end;
     }
-    for (Staging& s : q.st) {
-        int rc = retire(q, s, job.digests);
-        if (rc) return rc;
-    }
+    for (size_t k = 1; k < long_chunks.size(); ++k)
+        if ((rc = submit_chunk(q, job, q.st[2], q.stream[2], longs.data() + long_chunks[k].first,
+                               long_chunks[k].second - long_chunks[k].first, pack_ns)))
+            return rc;
+    for (Staging& s : q.st)
+        if ((rc = retire(q, s, job.digests))) return rc;
     return VIT_OK;
 }
 
@@ -311,7 +349,8 @@ int vit_hasher_create(const int* device_ids, int n_devices, vit_hasher** out)
             return VIT_ERR_NODEVICE;
         }
         if (r == hipSuccess) r = hipSetDevice(ids[k]);
-        if (r == hipSuccess) r = hipStreamCreateWithFlags(&q.stream, hipStreamNonBlocking);
+        for (hipStream_t& st : q.stream)
+            if (r == hipSuccess) r = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void**>(&q.d_status), 256);
         if (r == hipSuccess) r = hipMemset(q.d_status, 0, 256);
         if (r == hipSuccess) r = hipEventCreate(&q.ev_a);
@@ -333,12 +372,12 @@ void vit_hasher_destroy(vit_hasher* h)
     if (!h) return;
     for (Queue& q : h->queues) {
         (void)hipSetDevice(q.device);
-        if (q.stream) (void)hipStreamSynchronize(q.stream);
+        for (hipStream_t st : q.stream) if (st) (void)hipStreamSynchronize(st);
         for (Staging& s : q.st) free_staging(s);
         if (q.d_status) (void)hipFree(q.d_status);
         if (q.ev_a) (void)hipEventDestroy(q.ev_a);
         if (q.ev_b) (void)hipEventDestroy(q.ev_b);
-        if (q.stream) (void)hipStreamDestroy(q.stream);
+        for (hipStream_t st : q.stream) if (st) (void)hipStreamDestroy(st);
     }
     delete h;
 }
@@ -354,7 +393,8 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     if (k == "kernel") {
         if (value != VIT_KERNEL_LDS && value != VIT_KERNEL_LANE) return fail(h, VIT_ERR_ARG, "unknown kernel %llu", (unsigned long long)value);
         h->kernel = int(value);
-    } else if (k == "host_threshold_bytes") h->host_threshold = value;
+    } else if (k == "host_threshold_bytes") { h->host_threshold = value; h->host_policy = value ? 2 : 0; }
+    else if (k == "host_auto") { h->host_policy = value ? 1 : (h->host_threshold ? 2 : 0); }
     else if (k == "chunk_bytes") h->chunk_bytes = value < (1u << 20) ? (1u << 20) : value;
     else if (k == "pack_threads") h->pack_threads = value < 1 ? 1 : int(value > 256 ? 256 : value);
     else return fail(h, VIT_ERR_ARG, "unknown option '%s'", name);
@@ -367,6 +407,8 @@ int vit_hasher_get_stat(const vit_hasher* h, const char* name, uint64_t* value)
     const std::string k(name);
     if (k == "objects_gpu") *value = h->objects_gpu;
     else if (k == "objects_host") *value = h->objects_host;
+    else if (k == "bytes_host") *value = h->bytes_host;
+    else if (k == "last_host_threshold") *value = h->last_host_threshold;
     else if (k == "blocks_gpu") *value = h->blocks_gpu;
     else if (k == "bytes_h2d") *value = h->bytes_h2d;
     else if (k == "launches") *value = h->launches;
@@ -389,13 +431,30 @@ int vit_hash_objects(vit_hasher* h, const char* type, const uint8_t* const* data
     if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 objects in one call");
     const auto t0 = clk::now();
 
+    // One SHA-1 stream is serial: a lane sustains ~50 MB/s, a host core with SHA
+    // extensions ~2 GB/s, while a whole batch moves through pack + PCIe at tens
+    // of GB/s per GPU.  An object is therefore worth a lane only if its lane time
+    // hides inside the batch: auto policy keeps objects up to
+    // (batch bytes per queue) / 1024 on the GPU, within [64 KiB, 16 MiB];
+    // larger ones are hashed on host threads while the GPU batch runs.
+    uint64_t threshold = 0;
+    if (h->host_policy == 2) threshold = h->host_threshold;
+    else if (h->host_policy == 1) {
+        uint64_t total = 0;
+        for (uint64_t i = 0; i < n; ++i) total += len[i];
+        threshold = total / h->queues.size() / 1024;
+        threshold = std::min<uint64_t>(std::max<uint64_t>(threshold, 64u << 10), 16u << 20);
+    }
+    h->last_host_threshold = threshold;
+
     std::vector<uint32_t> nb(n);
     std::vector<uint64_t> gpu_idx, host_idx;
     gpu_idx.reserve(n);
+    uint64_t host_bytes = 0;
     for (uint64_t i = 0; i < n; ++i) {
         if (len[i] && !data[i]) return fail(h, VIT_ERR_ARG, "object %llu: null data with non-zero length", (unsigned long long)i);
         const uint64_t b = (tl + 1 + vit::decimal_digits(len[i]) + 1 + len[i] + 9 + 63) / 64;
-        if (h->host_threshold && len[i] > h->host_threshold) { host_idx.push_back(i); nb[i] = 0; continue; }
+        if (threshold && len[i] > threshold) { host_idx.push_back(i); host_bytes += len[i]; nb[i] = 0; continue; }
         if (b > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "object %llu too large for one lane", (unsigned long long)i);
         nb[i] = uint32_t(b);
         gpu_idx.push_back(i);
@@ -405,8 +464,9 @@ int vit_hash_objects(vit_hasher* h, const char* type, const uint8_t* const* data
     std::vector<std::thread> host_workers;
     std::atomic<size_t> next_host{0};
     if (!host_idx.empty()) {
-        unsigned hw = std::thread::hardware_concurrency();
-        size_t nt = std::min<size_t>(host_idx.size(), hw ? hw : 4);
+        // longest first, so the tail of the host work is short
+        std::stable_sort(host_idx.begin(), host_idx.end(), [&](uint64_t a, uint64_t b) { return len[a] > len[b]; });
+        const size_t nt = std::min<size_t>(host_idx.size(), size_t(h->pack_threads));
         for (size_t t = 0; t < nt; ++t)
             host_workers.emplace_back([&] {
                 for (size_t k; (k = next_host++) < host_idx.size();) {
@@ -415,6 +475,7 @@ int vit_hash_objects(vit_hasher* h, const char* type, const uint8_t* const* data
                 }
             });
         h->objects_host += host_idx.size();
+        h->bytes_host += host_bytes;
     }
 
     Job job{h, type, tl, data, len, nb.data(), digests};
@@ -518,15 +579,15 @@ int vit_hash_arena(vit_hasher* h, int dev, const void* arena, uint64_t arena_byt
     if (int rc = ensure_meta(*q, s, n)) return fail(h, rc, "%s", q->err.c_str());
     for (uint64_t i = 0; i < n; ++i) { s.h_off[i] = offsets[i] - lo; s.h_nb[i] = nblocks[i]; }
     const bool binned = vit::bin_order(s.h_nb, n, s.h_order);
-    HIP_TRY(h, hipMemcpyAsync(s.d_arena, static_cast<const uint8_t*>(arena) + lo, span, hipMemcpyHostToDevice, q->stream));
-    HIP_TRY(h, hipMemcpyAsync(s.d_off, s.h_off, n * 8, hipMemcpyHostToDevice, q->stream));
-    HIP_TRY(h, hipMemcpyAsync(s.d_nb, s.h_nb, n * 4, hipMemcpyHostToDevice, q->stream));
-    if (binned) HIP_TRY(h, hipMemcpyAsync(s.d_order, s.h_order, n * 4, hipMemcpyHostToDevice, q->stream));
+    HIP_TRY(h, hipMemcpyAsync(s.d_arena, static_cast<const uint8_t*>(arena) + lo, span, hipMemcpyHostToDevice, q->stream[0]));
+    HIP_TRY(h, hipMemcpyAsync(s.d_off, s.h_off, n * 8, hipMemcpyHostToDevice, q->stream[0]));
+    HIP_TRY(h, hipMemcpyAsync(s.d_nb, s.h_nb, n * 4, hipMemcpyHostToDevice, q->stream[0]));
+    if (binned) HIP_TRY(h, hipMemcpyAsync(s.d_order, s.h_order, n * 4, hipMemcpyHostToDevice, q->stream[0]));
     HIP_TRY(h, vit::launch_sha1(vit::KernelVariant(h->kernel),
                                 make_batch(*q, s.d_arena, span, s.d_off, s.d_nb, binned ? s.d_order : nullptr, n, s.d_dig),
-                                q->stream));
-    HIP_TRY(h, hipMemcpyAsync(s.h_dig, s.d_dig, n * 20, hipMemcpyDeviceToHost, q->stream));
-    HIP_TRY(h, hipStreamSynchronize(q->stream));
+                                q->stream[0]));
+    HIP_TRY(h, hipMemcpyAsync(s.h_dig, s.d_dig, n * 20, hipMemcpyDeviceToHost, q->stream[0]));
+    HIP_TRY(h, hipStreamSynchronize(q->stream[0]));
     std::memcpy(digests, s.h_dig, n * 20);
     h->objects_gpu += n; h->blocks_gpu += blocks; h->bytes_h2d += span + n * 16; ++h->launches;
     uint32_t st = 0;
@@ -545,7 +606,7 @@ int vit_hash_arena_device(vit_hasher* h, int dev, const void* d_arena, uint64_t 
     if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 objects in one call");
     if (reinterpret_cast<uintptr_t>(d_arena) & 15) return fail(h, VIT_ERR_RANGE, "arena not 16-byte aligned");
     HIP_TRY(h, hipSetDevice(q->device));
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : q->stream;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : q->stream[0];
     HIP_TRY(h, vit::launch_sha1(vit::KernelVariant(h->kernel),
                                 make_batch(*q, d_arena, arena_bytes, d_offsets, d_nblocks, d_order, n, d_digests), s));
     ++h->launches; h->objects_gpu += n;
@@ -596,7 +657,7 @@ int vit_device_download(vit_hasher* h, int dev, void* dst, const void* d_src, ui
     Queue* q = queue_of(h, dev);
     if (!q || (bytes && (!dst || !d_src))) return h ? fail(h, VIT_ERR_ARG, "bad arguments") : VIT_ERR_ARG;
     HIP_TRY(h, hipSetDevice(q->device));
-    HIP_TRY(h, hipStreamSynchronize(q->stream));
+    HIP_TRY(h, hipStreamSynchronize(q->stream[0]));
     HIP_TRY(h, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
     return VIT_OK;
 }
@@ -633,7 +694,7 @@ int vit_synth_arena_device(vit_hasher* h, int dev, const char* type, uint64_t se
     std::memset(s.type, 0, sizeof s.type);
     std::memcpy(s.type, type, tl);
     HIP_TRY(h, hipSetDevice(q->device));
-    HIP_TRY(h, vit::launch_synth(s, stream ? static_cast<hipStream_t>(stream) : q->stream));
+    HIP_TRY(h, vit::launch_synth(s, stream ? static_cast<hipStream_t>(stream) : q->stream[0]));
     return VIT_OK;
 }
 
@@ -645,11 +706,11 @@ int vit_time_hash_device(vit_hasher* h, int dev, const void* d_arena, uint64_t a
     if (!q || iters < 0 || warmup < 0 || (iters && !ms_each)) return h ? fail(h, VIT_ERR_ARG, "bad arguments") : VIT_ERR_ARG;
     for (int i = 0; i < warmup; ++i)
         if (int rc = vit_hash_arena_device(h, dev, d_arena, arena_bytes, d_offsets, d_nblocks, d_order, n, d_digests, nullptr)) return rc;
-    HIP_TRY(h, hipStreamSynchronize(q->stream));
+    HIP_TRY(h, hipStreamSynchronize(q->stream[0]));
     for (int i = 0; i < iters; ++i) {
-        HIP_TRY(h, hipEventRecord(q->ev_a, q->stream));
+        HIP_TRY(h, hipEventRecord(q->ev_a, q->stream[0]));
         if (int rc = vit_hash_arena_device(h, dev, d_arena, arena_bytes, d_offsets, d_nblocks, d_order, n, d_digests, nullptr)) return rc;
-        HIP_TRY(h, hipEventRecord(q->ev_b, q->stream));
+        HIP_TRY(h, hipEventRecord(q->ev_b, q->stream[0]));
         HIP_TRY(h, hipEventSynchronize(q->ev_b));
         HIP_TRY(h, hipEventElapsedTime(&ms_each[i], q->ev_a, q->ev_b));
         h->last_kernel_ns = uint64_t(double(ms_each[i]) * 1e6);
@@ -666,9 +727,9 @@ int vit_valu_peak(vit_hasher* h, int dev, uint32_t n_lanes, uint32_t blocks_per_
     HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&d_out), uint64_t(n_lanes) * 4));
     float best = 1e30f;
     for (int i = 0; i < iters + 1; ++i) {            // first launch is a warm-up
-        hipError_t e = hipEventRecord(q->ev_a, q->stream);
-        if (e == hipSuccess) e = vit::launch_valu_peak(d_out, n_lanes, blocks_per_lane, q->stream);
-        if (e == hipSuccess) e = hipEventRecord(q->ev_b, q->stream);
+        hipError_t e = hipEventRecord(q->ev_a, q->stream[0]);
+        if (e == hipSuccess) e = vit::launch_valu_peak(d_out, n_lanes, blocks_per_lane, q->stream[0]);
+        if (e == hipSuccess) e = hipEventRecord(q->ev_b, q->stream[0]);
         if (e == hipSuccess) e = hipEventSynchronize(q->ev_b);
         float t = 0;
         if (e == hipSuccess) e = hipEventElapsedTime(&t, q->ev_a, q->ev_b);

@@ -221,7 +221,12 @@ ObjectStore::ObjectStore(std::string objects_dir, std::vector<int> devices) : ob
     if (vit_hasher_create(devices.empty() ? nullptr : devices.data(), int(devices.size()), &hasher_) != VIT_OK) {
         std::cerr << "vit: cannot create the GPU hasher: " << vit_last_error(nullptr) << '\n';
         hasher_ = nullptr;
+        return;
     }
+    // Tuning knobs for experiments; the defaults are the library's.
+    if (const char* e = std::getenv("VIT_HOST_THRESHOLD")) vit_hasher_set_option(hasher_, "host_threshold_bytes", std::strtoull(e, nullptr, 10));
+    if (const char* e = std::getenv("VIT_CHUNK_MB")) vit_hasher_set_option(hasher_, "chunk_bytes", std::strtoull(e, nullptr, 10) << 20);
+    if (const char* e = std::getenv("VIT_KERNEL")) vit_hasher_set_option(hasher_, "kernel", std::strtoull(e, nullptr, 10));
 }
 
 ObjectStore::~ObjectStore()
