@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libvit_hash.so")
 CLI = os.path.join(HERE, "bin", "vit")
 
 LIB_SOURCES = ["kernels.hip", "hasher.cpp", "packer.cpp", "sha1_host.cpp"]
-CLI_SOURCES = ["object_store.cpp", "vit_cli.cpp"]
+CLI_SOURCES = ["object_store.cpp", "change_detect.cpp", "vit_cli.cpp"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-I" + os.path.join(ROOT, "include")]
 
 

@@ -172,6 +172,7 @@ vit::DeviceBatch make_batch(const Queue& q, const void* d_arena, uint64_t arena_
     b.n = uint32_t(n);
     b.digests = d_dig;
     b.status = q.d_status;
+    b.prio_blocks = 1024;          // 64 KiB and longer
     return b;
 }
 

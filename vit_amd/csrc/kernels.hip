@@ -112,6 +112,9 @@ __global__ __launch_bounds__(64) void sha1_lds_kernel(DeviceBatch b)
     const uint32_t my_row = (lane / OPI) * 1024u + (lane % OPI) * ROWB;
     const uint32_t max_nb = __builtin_amdgcn_readfirstlane(wave_max_u32(my_nb));
     const uint32_t nst    = (max_nb + BPS - 1) / BPS;
+    // A wave that carries a long object decides when the launch ends; let it win
+    // the issue arbitration against the short waves that share its SIMD.
+    if (b.prio_blocks && max_nb >= b.prio_blocks) __builtin_amdgcn_s_setprio(3);
     __syncthreads();             // table reads are done before the first DMA lands on them
 
     uint32_t h[5];

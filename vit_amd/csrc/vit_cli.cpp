@@ -7,12 +7,15 @@
 //   vit commit-tree <tree> -p <parent> -m <message>   reference src/main.cpp:165-186
 //   vit cat-file -p <hash>               reference src/main.cpp:68-88
 //   vit ls-tree <hash> --name-only|-l    reference src/main.cpp:122-153
+//   vit diff-tree <tree-or-commit>       which worktree files differ from a stored tree, decided by id
+//                                        (hash-based form of reference src/utils/change_analyzer.cpp:56-98)
 //
 // stdout carries exactly what the reference prints (the id and a newline);
 // the exit status is 0 on success, 1 on failure.  Author name and e-mail come
 // from the reference's ".vitconfig" (three whitespace separated fields,
 // src/main.cpp:35-41) or $VIT_AUTHOR / $VIT_EMAIL; $VIT_COMMIT_TIME pins the
 // clock for reproducible commits; $VIT_DEVICES picks the GPUs.
+#include "change_detect.hpp"
 #include "object_store.hpp"
 
 #include <cstdlib>
@@ -129,6 +132,26 @@ bool cmdLsTree(int argc, char** argv)
     return true;
 }
 
+bool cmdDiffTree(int argc, char** argv)
+{
+    if (argc < 3) { std::cerr << "Usage: diff-tree <tree-or-commit hash>\n"; return false; }
+    std::string tree = argv[2];
+    const std::string obj = readObject(tree);
+    if (obj.empty()) return false;
+    if (obj.rfind("commit ", 0) == 0) {                     // take the commit's tree line
+        const size_t at = obj.find("tree ");
+        if (at == std::string::npos || at + 45 > obj.size()) { std::cerr << "Invalid commit: " << tree << '\n'; return false; }
+        tree = obj.substr(at + 5, 40);
+    }
+    const vit::ChangeSet cs = vit::detectChanges(vit::defaultStore(), tree, ".");
+    if (!cs.ok) return false;
+    for (const vit::PathChange& c : cs.changes)
+        std::cout << (c.changeType == vit::ChangeType::ADDED ? 'A' : c.changeType == vit::ChangeType::DELETED ? 'D' : 'M')
+                  << '\t' << c.filePath << '\n';
+    std::cerr << cs.totalFilesAnalyzed << " files analyzed, " << cs.changes.size() << " changed\n";
+    return true;
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -144,6 +167,7 @@ int main(int argc, char** argv)
     else if (cmd == "commit-tree") ok = cmdCommitTree(argc, argv);
     else if (cmd == "cat-file") ok = cmdCatFile(argc, argv);
     else if (cmd == "ls-tree") ok = cmdLsTree(argc, argv);
+    else if (cmd == "diff-tree") ok = cmdDiffTree(argc, argv);
     else { std::cerr << "Unknown command " << cmd << '\n'; return EXIT_FAILURE; }
     return ok ? EXIT_SUCCESS : EXIT_FAILURE;
 }
