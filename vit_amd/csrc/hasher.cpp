@@ -106,6 +106,20 @@ int fail(const vit_hasher* h, int code, const char* fmt, ...)
         }                                                                                     \
     } while (0)
 
+// Joins on scope exit, so an early return or an exception never leaves a
+// running thread behind.
+struct ThreadGroup {
+    std::vector<std::thread> t;
+    ~ThreadGroup() { for (auto& x : t) if (x.joinable()) x.join(); }
+    void join() { for (auto& x : t) if (x.joinable()) x.join(); }
+};
+
+// Nothing may propagate out of an extern "C" entry point.
+#define VIT_NOEXCEPT_BEGIN try {
+#define VIT_NOEXCEPT_END(h)                                                                    \
+    } catch (const std::bad_alloc&) { return fail((h), VIT_ERR_NOMEM, "out of host memory"); }  \
+      catch (const std::exception& e_) { return fail((h), VIT_ERR_HIP, "internal error: %s", e_.what()); }
+
 Queue* queue_of(vit_hasher* h, int dev)
 {
     if (!h || dev < 0 || size_t(dev) >= h->queues.size()) return nullptr;
@@ -392,7 +406,7 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     if (!h || !name) return VIT_ERR_ARG;
     const std::string k(name);
     if (k == "kernel") {
-        if (value != VIT_KERNEL_LDS && value != VIT_KERNEL_LANE) return fail(h, VIT_ERR_ARG, "unknown kernel %llu", (unsigned long long)value);
+        if (value > 3) return fail(h, VIT_ERR_ARG, "unknown kernel %llu", (unsigned long long)value);
         h->kernel = int(value);
     } else if (k == "host_threshold_bytes") { h->host_threshold = value; h->host_policy = value ? 2 : 0; }
     else if (k == "host_auto") { h->host_policy = value ? 1 : (h->host_threshold ? 2 : 0); }
@@ -431,6 +445,7 @@ int vit_hash_objects(vit_hasher* h, const char* type, const uint8_t* const* data
     if (!data || !len || !digests) return fail(h, VIT_ERR_ARG, "null argument");
     if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 objects in one call");
     const auto t0 = clk::now();
+    VIT_NOEXCEPT_BEGIN
 
     // One SHA-1 stream is serial: a lane sustains ~50 MB/s, a host core with SHA
     // extensions ~2 GB/s, while a whole batch moves through pack + PCIe at tens
@@ -462,14 +477,14 @@ int vit_hash_objects(vit_hasher* h, const char* type, const uint8_t* const* data
     }
 
     // Oversized objects: one SHA-1 stream each on host threads, beside the GPU batch.
-    std::vector<std::thread> host_workers;
+    ThreadGroup host_workers;
     std::atomic<size_t> next_host{0};
     if (!host_idx.empty()) {
         // longest first, so the tail of the host work is short
         std::stable_sort(host_idx.begin(), host_idx.end(), [&](uint64_t a, uint64_t b) { return len[a] > len[b]; });
         const size_t nt = std::min<size_t>(host_idx.size(), size_t(h->pack_threads));
         for (size_t t = 0; t < nt; ++t)
-            host_workers.emplace_back([&] {
+            host_workers.t.emplace_back([&] {
                 for (size_t k; (k = next_host++) < host_idx.size();) {
                     const uint64_t i = host_idx[k];
                     vit::host_object_id(type, data[i], len[i], digests + i * 20);
@@ -487,12 +502,15 @@ int vit_hash_objects(vit_hasher* h, const char* type, const uint8_t* const* data
     if (h->queues.size() == 1) {
         rcs[0] = run_queue(h->queues[0], job, parts[0], &pack_ns[0]);
     } else {
-        std::vector<std::thread> workers;
+        ThreadGroup workers;
         for (size_t k = 0; k < h->queues.size(); ++k)
-            workers.emplace_back([&, k] { rcs[k] = run_queue(h->queues[k], job, parts[k], &pack_ns[k]); });
-        for (auto& w : workers) w.join();
+            workers.t.emplace_back([&, k] {
+                try { rcs[k] = run_queue(h->queues[k], job, parts[k], &pack_ns[k]); }
+                catch (const std::exception& e) { h->queues[k].err = e.what(); rcs[k] = VIT_ERR_NOMEM; }
+            });
+        workers.join();
     }
-    for (auto& w : host_workers) w.join();
+    host_workers.join();
     h->last_pack_ns = 0;
     for (uint64_t p : pack_ns) h->last_pack_ns = std::max(h->last_pack_ns, p);
     h->last_total_ns = ns_since(t0);
@@ -505,6 +523,7 @@ int vit_hash_objects(vit_hasher* h, const char* type, const uint8_t* const* data
         if (st) return fail(h, VIT_ERR_DEVICE_STATUS, "device queue %zu flagged status %u", k, st);
     }
     return VIT_OK;
+    VIT_NOEXCEPT_END(h)
 }
 
 int vit_hash_blobs(vit_hasher* h, const uint8_t* const* data, const uint64_t* len, uint64_t n, uint8_t* digests)
@@ -522,6 +541,7 @@ int vit_host_object_id(const char* type, const uint8_t* data, uint64_t len, uint
 int vit_shard_plan(const uint32_t* nblocks, uint64_t n, int n_queues, uint32_t* queue_of)
 {
     if (n_queues < 1 || (n && (!nblocks || !queue_of))) return VIT_ERR_ARG;
+    VIT_NOEXCEPT_BEGIN
     std::vector<uint64_t> idx(n);
     for (uint64_t i = 0; i < n; ++i) idx[i] = i;
     std::vector<std::vector<uint64_t>> parts;
@@ -529,6 +549,7 @@ int vit_shard_plan(const uint32_t* nblocks, uint64_t n, int n_queues, uint32_t* 
     for (size_t q = 0; q < parts.size(); ++q)
         for (uint64_t i : parts[q]) queue_of[i] = uint32_t(q);
     return VIT_OK;
+    VIT_NOEXCEPT_END(nullptr)
 }
 
 int vit_arena_alloc(vit_hasher* h, uint64_t bytes, void** out)
@@ -555,6 +576,7 @@ int vit_hash_arena(vit_hasher* h, int dev, const void* arena, uint64_t arena_byt
     if (n == 0) return VIT_OK;
     if (!arena || !offsets || !nblocks || !digests) return fail(h, VIT_ERR_ARG, "null argument");
     if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 objects in one call");
+    VIT_NOEXCEPT_BEGIN
     uint64_t lo = ~0ull, hi = 0, blocks = 0;
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t sz = uint64_t(nblocks[i]) * 64;
@@ -595,6 +617,7 @@ int vit_hash_arena(vit_hasher* h, int dev, const void* arena, uint64_t arena_byt
     if (int rc = vit_device_status(h, dev, &st)) return rc;
     if (st) return fail(h, VIT_ERR_DEVICE_STATUS, "device queue %d flagged status %u", dev, st);
     return VIT_OK;
+    VIT_NOEXCEPT_END(h)
 }
 
 int vit_hash_arena_device(vit_hasher* h, int dev, const void* d_arena, uint64_t arena_bytes, const uint64_t* d_offsets,

@@ -190,7 +190,9 @@ hipError_t launch_sha1(KernelVariant v, const DeviceBatch& b, hipStream_t stream
         hipLaunchKernelGGL(sha1_lane_kernel, dim3(grid), dim3(256), 0, stream, b);
     } else {
         const uint32_t grid = (b.n + 63u) / 64u;
-        hipLaunchKernelGGL(sha1_lds_kernel<2>, dim3(grid), dim3(64), 0, stream, b);
+        if (int(v) == 2) hipLaunchKernelGGL(sha1_lds_kernel<1>, dim3(grid), dim3(64), 0, stream, b);
+        else if (int(v) == 3) hipLaunchKernelGGL(sha1_lds_kernel<4>, dim3(grid), dim3(64), 0, stream, b);
+        else hipLaunchKernelGGL(sha1_lds_kernel<2>, dim3(grid), dim3(64), 0, stream, b);
     }
     return hipGetLastError();
 }

@@ -110,6 +110,7 @@ int vit_arena_pack(const char* type, const uint8_t* const* data, const uint64_t*
 {
     const uint32_t tl = vit::type_len_checked(type);
     if (!tl || (n && (!data || !len || !arena || !offsets || !nblocks))) return VIT_ERR_ARG;
+    try {
     std::vector<uint64_t> prefix(n + 1, 0);
     for (uint64_t i = 0; i < n; ++i) {
         if (len[i] && !data[i]) return VIT_ERR_ARG;
@@ -130,13 +131,15 @@ int vit_arena_pack(const char* type, const uint8_t* const* data, const uint64_t*
         for (uint64_t i = b; i < e; ++i) vit::pack_one(type, tl, data[i], len[i], base + offsets[i], nblocks[i]);
     });
     return VIT_OK;
+    } catch (const std::exception&) { return VIT_ERR_NOMEM; }     // nothing propagates out of the C ABI
 }
 
 int vit_bin_order(const uint32_t* nblocks, uint64_t n, uint32_t* order)
 {
     if (n && (!nblocks || !order)) return VIT_ERR_ARG;
     if (n > 0xFFFFFFFFull) return VIT_ERR_RANGE;
-    return vit::bin_order(nblocks, n, order) ? 1 : 0;
+    try { return vit::bin_order(nblocks, n, order) ? 1 : 0; }
+    catch (const std::exception&) { return VIT_ERR_NOMEM; }
 }
 
 void vit_synth_bytes(uint64_t seed, uint64_t index, uint8_t* dst, uint64_t len)
