@@ -38,6 +38,35 @@ def make_c1(root):
     return n, n * 4096
 
 
+def _c2_part(args):
+    root, lo, hi = args
+    step = 4096
+    for base in range(lo, hi, step):
+        top = min(base + step, hi)
+        blob = O.synth_fill_many(0x5EED0002, base, top - base, 4096, threads=1)
+        for i in range(base, top):
+            d = os.path.join(root, "d%03d" % (i // 1000))
+            if i % 1000 == 0 or i == lo:
+                os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "f%07d.bin" % i), "wb") as f:
+                f.write(blob[(i - base) * 4096:(i - base + 1) * 4096].tobytes())
+    return hi - lo
+
+
+def make_c2(root, n_files):
+    """The headline worktree: n files x 4,096 B (blob i = synthetic stream i of seed 0x5EED0002, the same
+    blobs bench.py hashes), 1,000 per directory; on this layout the reference's tree id is also git's."""
+    import multiprocessing as mp
+    procs = 8
+    cuts = [n_files * k // procs // 1000 * 1000 for k in range(procs)] + [n_files]
+    with mp.Pool(procs) as pool:
+        done = 0
+        for part in pool.imap_unordered(_c2_part, [(root, cuts[k], cuts[k + 1]) for k in range(procs)]):
+            done += part
+            print("generated %d files" % done, file=sys.stderr, flush=True)
+    return n_files, n_files * 4096
+
+
 def make_c3(root, n_files):
     """Linux-kernel-like: lognormal sizes (median 4.5 KB, sigma 1.55) clipped to 32 MiB and rescaled to
     ~15 KB mean; ~n/16 directories, three levels; names avoid the cases where the reference and git differ."""
@@ -74,8 +103,9 @@ def run_vit(wt, args=()):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["c1", "c3"])
-    ap.add_argument("--files", type=int, default=80000)
+    ap.add_argument("config", choices=["c1", "c2", "c3"])
+    ap.add_argument("--files", type=int, default=None, help="c2: default 1,000,000; c3: default 80,000")
+    ap.add_argument("--git", action="store_true", help="also run real `git add -A && git write-tree` on the worktree")
     ap.add_argument("--dir", default=None, help="where to build the worktree (default: a temp dir, /dev/shm if present)")
     ap.add_argument("--skip-reference", action="store_true")
     a = ap.parse_args()
@@ -84,9 +114,16 @@ def main():
     os.makedirs(wt, exist_ok=True)
     try:
         t0 = time.perf_counter()
-        n, total = make_c1(wt) if a.config == "c1" else make_c3(wt, a.files)
+        if a.config == "c1":
+            n, total = make_c1(wt)
+        elif a.config == "c2":
+            n, total = make_c2(wt, a.files or 1_000_000)
+        else:
+            n, total = make_c3(wt, a.files or 80000)
         gen_s = time.perf_counter() - t0
         out = {"config": a.config, "files": n, "bytes": total, "generate_s": round(gen_s, 2)}
+        say = lambda m: print(m, file=sys.stderr, flush=True)
+        say("worktree ready (%d files, %.1f s); CPU restatement with store ..." % (n, gen_s))
 
         # CPU path, single thread, as the reference does it: hash + deflate + store per object
         objdir = os.path.join(base, "oracle_objects")
@@ -94,6 +131,7 @@ def main():
         want, nb, nt = O.write_tree(wt, objdir)
         cpu_s = time.perf_counter() - t0
         shutil.rmtree(objdir, ignore_errors=True)
+        say("... %.1f s; CPU restatement, ids only ..." % cpu_s)
         t0 = time.perf_counter()
         want2, _, _ = O.write_tree(wt, None)
         cpu_hash_s = time.perf_counter() - t0
@@ -102,6 +140,7 @@ def main():
                                   "hash_only_s": round(cpu_hash_s, 3), "cores": 1,
                                   "objects_per_s": round((nb + nt) / cpu_s, 1)}
         if O.ref_lib() is not None and not a.skip_reference:
+            say("reference's own writeTree ...")
             cwd = os.getcwd()
             os.makedirs(os.path.join(wt, ".git", "objects"), exist_ok=True)
             os.chdir(wt)
@@ -116,6 +155,7 @@ def main():
                                      "objects_per_s": round((nb + nt) / ref_s, 1)}
             assert ref == want.hex()
 
+        say("vit write-tree (GPU) ...")
         root, dt, stats = run_vit(wt)
         shutil.rmtree(os.path.join(wt, ".git"))
         root2, dt2, stats2 = run_vit(wt, ["--no-store"])
@@ -123,6 +163,14 @@ def main():
                                  "objects_per_s": round((nb + nt) / dt, 1),
                                  "ids_only_wall_s": round(dt2, 3), "ids_only_stats": stats2}
         out["match"] = bool(root == want.hex() == root2)
+        if a.git and shutil.which("git"):
+            say("git add -A && git write-tree ...")
+            shutil.rmtree(os.path.join(wt, ".git"), ignore_errors=True)
+            t0 = time.perf_counter()
+            subprocess.check_call(["git", "init", "-q", "."], cwd=wt)
+            subprocess.check_call(["git", "-c", "core.fsync=none", "-c", "gc.auto=0", "add", "-A"], cwd=wt)
+            g = subprocess.check_output(["git", "write-tree"], cwd=wt).decode().strip()
+            out["git"] = {"write_tree": g, "seconds": round(time.perf_counter() - t0, 2), "equals_vit": g == root}
         print(json.dumps(out), flush=True)
         if not out["match"]:
             sys.exit(1)

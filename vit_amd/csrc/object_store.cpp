@@ -19,6 +19,9 @@
 #include <queue>
 #include <sstream>
 #include <thread>
+#include <cerrno>
+#include <fcntl.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 namespace fs = std::filesystem;
@@ -134,30 +137,40 @@ bool writeFileAtomic(const std::string& path, const std::string& bytes)
 {
     static std::atomic<uint64_t> serial{0};
     const std::string tmp = path + ".tmp" + std::to_string(uint64_t(getpid())) + "_" + std::to_string(serial++);
-    {
-        std::ofstream f(tmp, std::ios::binary);
-        if (!f) return false;
-        f.write(bytes.data(), std::streamsize(bytes.size()));
-        if (!f) { std::remove(tmp.c_str()); return false; }
+    const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+    if (fd < 0) return false;
+    size_t put = 0;
+    while (put < bytes.size()) {
+        const ssize_t w = ::write(fd, bytes.data() + put, bytes.size() - put);
+        if (w < 0 && errno == EINTR) continue;
+        if (w <= 0) { ::close(fd); ::unlink(tmp.c_str()); return false; }
+        put += size_t(w);
     }
-    std::error_code ec;
-    fs::rename(tmp, path, ec);
-    if (ec) { std::remove(tmp.c_str()); return false; }
+    if (::close(fd) != 0 || ::rename(tmp.c_str(), path.c_str()) != 0) { ::unlink(tmp.c_str()); return false; }
     return true;
 }
 
-std::string slurp(const std::string& path)
+// Whole file into a string.  size_hint is the size seen during the walk: the
+// buffer is one byte larger, so a file that still has that size is read, and
+// its end detected, by a single read() (open + read + close per file; a million
+// small files are bound by system calls, not by bytes).
+std::string slurp(const std::string& path, uint64_t size_hint)
 {
     // reference src/commit.cpp:151-152: an unreadable file yields empty content.
-    std::ifstream f(path, std::ios::binary);
-    if (!f) return {};
-    f.seekg(0, std::ios::end);
-    const std::streamoff n = f.tellg();
-    if (n <= 0) { std::ostringstream ss; f.clear(); f.seekg(0); ss << f.rdbuf(); return ss.str(); }
-    std::string s(size_t(n), '\0');
-    f.seekg(0);
-    f.read(&s[0], n);
-    s.resize(size_t(f.gcount()));
+    const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return {};
+    std::string s(size_t(size_hint) + 1, '\0');
+    size_t got = 0;
+    for (;;) {
+        if (got == s.size()) s.resize(s.size() * 2);                       // the file grew since the walk
+        const ssize_t r = ::read(fd, &s[got], s.size() - got);
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) break;
+        got += size_t(r);
+        if (got < s.size() && got >= size_hint) break;                      // short read at or past the expected size: EOF
+    }
+    ::close(fd);
+    s.resize(got);
     return s;
 }
 
@@ -177,36 +190,66 @@ struct Ent { std::string name; bool is_dir; size_t ref; };
 struct DirNode { std::string path; int depth; std::vector<Ent> ents; uint8_t id[20]; };
 struct FileRec { std::string path; uint64_t size; uint8_t id[20]; };
 
-// Depth-first walk with the reference's rules (src/commit.cpp:143-161): skip
+// What one directory listing found, before indices are assigned.
+struct Listed { std::string name; std::string path; bool is_dir; uint64_t size; };
+
+// List one directory with the reference's rules (src/commit.cpp:143-161): skip
 // entries named ".git"; status checks follow symlinks; anything that is neither
-// a regular file nor a directory makes the whole tree fail.
-bool walk(const std::string& dir, int depth, std::vector<DirNode>& dirs, std::vector<FileRec>& files, size_t& self)
+// a regular file nor a directory makes the whole tree fail (:160).
+bool listDir(const std::string& dir, std::vector<Listed>& out)
 {
-    self = dirs.size();
-    dirs.push_back(DirNode{dir, depth, {}, {}});
     std::error_code ec;
     fs::directory_iterator it(dir, ec), end;
     if (ec) { std::cerr << "cannot read directory " << dir << ": " << ec.message() << '\n'; return false; }
-    std::vector<Ent> ents;
     for (; it != end; it.increment(ec)) {
         if (ec) return false;
-        const std::string name = it->path().filename().string();
+        std::string name = it->path().filename().string();
         if (name == ".git") continue;
         std::error_code sec;
         if (it->is_regular_file(sec)) {
             uint64_t sz = it->file_size(sec);
             if (sec) sz = 0;
-            ents.push_back(Ent{name, false, files.size()});
-            files.push_back(FileRec{it->path().string(), sz, {}});
+            out.push_back(Listed{std::move(name), it->path().string(), false, sz});
         } else if (it->is_directory(sec)) {
-            size_t child;
-            if (!walk(it->path().string(), depth + 1, dirs, files, child)) return false;
-            ents.push_back(Ent{name, true, child});
+            out.push_back(Listed{std::move(name), it->path().string(), true, 0});
         } else {
-            return false;                                 // reference: empty hash -> return {}
+            return false;
         }
     }
-    dirs[self].ents = std::move(ents);
+    return true;
+}
+
+// Breadth-first walk: all directories of one depth are listed in parallel on
+// the pool, then their entries get file / directory indices serially.  dirs[0]
+// is the root.  (The reference recurses depth-first, one entry at a time; the
+// order of discovery does not enter any id, entries are sorted by name later.)
+bool walk(const std::string& root, Pool& pool, std::vector<DirNode>& dirs, std::vector<FileRec>& files)
+{
+    dirs.push_back(DirNode{root, 0, {}, {}});
+    std::vector<size_t> level(1, 0);
+    for (int depth = 0; !level.empty(); ++depth) {
+        std::vector<std::vector<Listed>> found(level.size());
+        std::atomic<bool> ok{true};
+        pool.forEach(level.size(), [&](size_t k) { if (!listDir(dirs[level[k]].path, found[k])) ok = false; });
+        if (!ok) return false;
+        std::vector<size_t> next;
+        for (size_t k = 0; k < level.size(); ++k) {
+            std::vector<Ent> ents;
+            ents.reserve(found[k].size());
+            for (Listed& e : found[k]) {
+                if (e.is_dir) {
+                    ents.push_back(Ent{std::move(e.name), true, dirs.size()});
+                    next.push_back(dirs.size());
+                    dirs.push_back(DirNode{std::move(e.path), depth + 1, {}, {}});
+                } else {
+                    ents.push_back(Ent{std::move(e.name), false, files.size()});
+                    files.push_back(FileRec{std::move(e.path), e.size, {}});
+                }
+            }
+            dirs[level[k]].ents = std::move(ents);
+        }
+        level.swap(next);
+    }
     return true;
 }
 
@@ -258,15 +301,6 @@ bool ObjectStore::hashObjects(const std::string& type, const std::vector<const s
     return true;
 }
 
-bool ObjectStore::storeFramed(const std::string& hex, const std::string& type, const std::string& content) const
-{
-    std::string z;
-    if (!deflateFramed(type, content, z)) { std::cerr << "Compression failed\n"; return false; }
-    std::error_code ec;
-    fs::create_directories(objects_dir_ + '/' + hex.substr(0, 2), ec);
-    return writeFileAtomic(objectPath(hex), z);
-}
-
 std::vector<std::string> ObjectStore::writeObjects(const std::string& type, const std::vector<std::string>& contents)
 {
     const size_t n = contents.size();
@@ -275,35 +309,39 @@ std::vector<std::string> ObjectStore::writeObjects(const std::string& type, cons
     std::vector<const std::string*> view(n);
     for (size_t i = 0; i < n; ++i) view[i] = &contents[i];
 
-    // Deflate needs no id, so it runs on the pool while the GPU hashes; only the
-    // file name waits for the digest.
-    std::vector<std::string> z(store_ ? n : 0);
-    std::atomic<bool> z_ok{true};
-    Pool pool(store_ && n > 1 ? io_threads_ : 1);
+    // Ids first: the GPU batch takes milliseconds per GB, and knowing the id lets
+    // the (far more expensive) deflate be skipped for objects the store already
+    // holds.  The reference always rewrites (src/commit.cpp:110); the stored
+    // bytes are the same either way.
     const auto t0 = clk::now();
-    if (store_)
-        for (size_t s = 0, slices = std::min<size_t>(n, size_t(io_threads_) * 4); s < slices; ++s)
-            pool.submit([&, s, slices] {
-                for (size_t i = n * s / slices; i < n * (s + 1) / slices; ++i)
-                    if (!deflateFramed(type, contents[i], z[i])) z_ok = false;
-            });
     std::vector<uint8_t> raw;
-    const bool hashed = hashObjects(type, view, raw);
+    if (!hashObjects(type, view, raw)) return ids;
     stats_.hash_s += since(t0);
-    pool.wait();
-    if (!hashed) return ids;
-    if (!z_ok) { std::cerr << "Compression failed\n"; return ids; }
 
     ids.resize(n);
     for (size_t i = 0; i < n; ++i) ids[i] = toHex(&raw[i * 20], 20);
     if (store_) {
-        std::atomic<bool> w_ok{true};
+        bool need[256] = {false};                         // the "aa" fan-out directories this batch touches
+        for (size_t i = 0; i < n; ++i) need[raw[i * 20]] = true;
+        for (int d = 0; d < 256; ++d)
+            if (need[d]) {
+                const uint8_t byte = uint8_t(d);
+                std::error_code ec;
+                fs::create_directories(objects_dir_ + '/' + toHex(&byte, 1), ec);
+            }
+        std::atomic<int> failed{0};                       // 1 compression, 2 write
+        std::atomic<uint64_t> skipped{0};
+        Pool pool(n > 1 ? io_threads_ : 1);
         pool.forEach(n, [&](size_t i) {
-            std::error_code ec;
-            fs::create_directories(objects_dir_ + '/' + ids[i].substr(0, 2), ec);
-            if (!writeFileAtomic(objectPath(ids[i]), z[i])) w_ok = false;
+            const std::string path = objectPath(ids[i]);
+            if (skip_existing_ && ::access(path.c_str(), F_OK) == 0) { ++skipped; return; }
+            std::string z;
+            if (!deflateFramed(type, contents[i], z)) { failed = 1; return; }
+            if (!writeFileAtomic(path, z)) failed = 2;
         });
-        if (!w_ok) { std::cerr << "vit: writing objects under " << objects_dir_ << " failed\n"; return {}; }
+        stats_.skipped += skipped;
+        if (failed == 1) { std::cerr << "Compression failed\n"; return {}; }
+        if (failed == 2) { std::cerr << "vit: writing objects under " << objects_dir_ << " failed\n"; return {}; }
     }
     stats_.deflate_store_s += since(t0);
     return ids;
@@ -324,20 +362,24 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
 
     std::vector<DirNode> dirs;
     std::vector<FileRec> files;
-    size_t root;
+    std::vector<std::string> contents;                     // declared before the pool that fills it
+    Pool reader(io_threads_);
+    const size_t root = 0;
     auto t0 = clk::now();
-    if (!walk(directoryPath, 0, dirs, files, root)) return {};
+    if (!walk(directoryPath, reader, dirs, files)) return {};
     stats_.walk_s = since(t0);
 
-    // ---- blobs: bounded batches: read (pool) -> hash on GPU || deflate (pool) -> store (pool)
-    Pool reader(io_threads_);
+    // ---- blobs: bounded batches: read (pool) -> ids on the GPU -> deflate + store
+    // what is new (pool).  The three steps run back to back: every one of them
+    // except the GPU batch is bound by host cores, so overlapping them only
+    // oversubscribes the cores (measured: slower).
     for (size_t pos = 0; pos < files.size();) {
         size_t end = pos;
         uint64_t bytes = 0;
         while (end < files.size() && (end == pos || bytes + files[end].size <= batch_bytes_)) bytes += files[end++].size;
-        std::vector<std::string> contents(end - pos);
+        contents.assign(end - pos, std::string());
         t0 = clk::now();
-        reader.forEach(end - pos, [&](size_t i) { contents[i] = slurp(files[pos + i].path); });
+        reader.forEach(end - pos, [&](size_t i) { contents[i] = slurp(files[pos + i].path, files[pos + i].size); });
         stats_.read_s += since(t0);
         std::vector<std::string> ids = writeObjects("blob", contents);
         if (ids.size() != contents.size()) return {};

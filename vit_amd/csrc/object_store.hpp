@@ -30,6 +30,7 @@ namespace vit {
 
 struct StoreStats {
     uint64_t blobs = 0, trees = 0, bytes = 0;
+    uint64_t skipped = 0;                      // objects already in the store (not deflated or written again)
     double walk_s = 0, read_s = 0, hash_s = 0, deflate_store_s = 0, total_s = 0;
 };
 
@@ -66,6 +67,10 @@ public:
     bool hashObjects(const std::string& type, const std::vector<const std::string*>& contents, std::vector<uint8_t>& out);
 
     void setStoreObjects(bool on) { store_ = on; }          // false: compute ids only (benchmarks)
+    // true (default): an object whose file already exists is not deflated and written again — its name
+    // is the hash of its content, so the bytes would be the same.  false: always rewrite, as the
+    // reference does (src/commit.cpp:108-111).
+    void setSkipExisting(bool on) { skip_existing_ = on; }
     void setIoThreads(int n) { io_threads_ = n < 1 ? 1 : n; }
     void setBatchBytes(uint64_t b) { batch_bytes_ = b; }
     const StoreStats& lastStats() const { return stats_; }
@@ -73,10 +78,10 @@ public:
     std::string objectPath(const std::string& hash) const;
 
 private:
-    bool storeFramed(const std::string& hex, const std::string& type, const std::string& content) const;
     std::string objects_dir_;
     vit_hasher* hasher_ = nullptr;
     bool store_ = true;
+    bool skip_existing_ = true;
     int io_threads_ = 8;
     uint64_t batch_bytes_ = 1ull << 30;
     StoreStats stats_;

@@ -3,7 +3,7 @@
 //
 //   vit init
 //   vit hash-object -w <file>            reference src/main.cpp:90-120
-//   vit write-tree [--stats] [--no-store] reference src/main.cpp:155-163
+//   vit write-tree [--stats] [--no-store] [--rewrite]    reference src/main.cpp:155-163
 //   vit commit-tree <tree> -p <parent> -m <message>   reference src/main.cpp:165-186
 //   vit cat-file -p <hash>               reference src/main.cpp:68-88
 //   vit ls-tree <hash> --name-only|-l    reference src/main.cpp:122-153
@@ -73,6 +73,7 @@ bool cmdWriteTree(int argc, char** argv)
     for (int i = 2; i < argc; ++i) {
         if (!std::strcmp(argv[i], "--stats")) stats = true;
         else if (!std::strcmp(argv[i], "--no-store")) vit::defaultStore().setStoreObjects(false);
+        else if (!std::strcmp(argv[i], "--rewrite")) vit::defaultStore().setSkipExisting(false);
         else { std::cerr << "Unknown flag: " << argv[i] << '\n'; return false; }
     }
     const std::string id = writeTree(".");
@@ -80,7 +81,8 @@ bool cmdWriteTree(int argc, char** argv)
     std::cout << id << '\n';
     if (stats) {
         const vit::StoreStats& s = vit::defaultStore().lastStats();
-        std::cerr << "blobs " << s.blobs << " trees " << s.trees << " bytes " << s.bytes << " | walk " << s.walk_s
+        std::cerr << "blobs " << s.blobs << " trees " << s.trees << " bytes " << s.bytes << " already-stored " << s.skipped
+                  << " | walk " << s.walk_s
                   << " s read " << s.read_s << " s hash " << s.hash_s << " s hash+deflate+store " << s.deflate_store_s
                   << " s total " << s.total_s << " s\n";
     }
