@@ -74,6 +74,40 @@ KERNEL(k_mul_u24,    "v_mul_u32_u24 %0, %0, %1")
 KERNEL(k_mul_lo,     "v_mul_lo_u32 %0, %0, %1")
 KERNEL(k_pk_add_u16, "v_pk_add_u16 %0, %0, %1")
 
+// Two-instruction mixes: does a 2-cycle-class op keep its rate next to 4-cycle-class ops?
+// GROUPED: 16 x A then 16 x B; ALTERNATE: A, B, A, B ... on different registers.
+#define KERNEL2(NAME, ASM_A, ASM_B, ALT)                                                          \
+    __global__ __launch_bounds__(256) void NAME(uint32_t* out, int iters)                         \
+    {                                                                                             \
+        uint32_t r[16];                                                                           \
+        uint32_t x = threadIdx.x * 2654435761u + blockIdx.x, y = x ^ 0x9E3779B9u;                 \
+        for (int i = 0; i < 16; ++i) r[i] = x + i * 77u;                                          \
+        for (int it = 0; it < iters; ++it) {                                                      \
+            _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                       \
+                if (ALT) {                                                                        \
+                    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                              \
+                        asm volatile(ASM_A : "+v"(r[i]) : "v"(x), "v"(y) : "vcc", "s4");          \
+                        asm volatile(ASM_B : "+v"(r[(i + 8) & 15]) : "v"(x), "v"(y) : "vcc", "s4"); \
+                    }                                                                             \
+                } else {                                                                          \
+                    _Pragma("unroll") for (int i = 0; i < 16; ++i)                                \
+                        asm volatile(ASM_A : "+v"(r[i]) : "v"(x), "v"(y) : "vcc", "s4");          \
+                    _Pragma("unroll") for (int i = 0; i < 16; ++i)                                \
+                        asm volatile(ASM_B : "+v"(r[i]) : "v"(x), "v"(y) : "vcc", "s4");          \
+                }                                                                                 \
+            }                                                                                     \
+        }                                                                                         \
+        uint32_t s = 0;                                                                           \
+        for (int i = 0; i < 16; ++i) s ^= r[i];                                                   \
+        out[blockIdx.x * 256 + threadIdx.x] = s;                                                  \
+    }
+KERNEL2(k2_xor_align_grp, "v_xor_b32 %0, %0, %1", "v_alignbit_b32 %0, %0, %0, 27", 0)
+KERNEL2(k2_xor_align_alt, "v_xor_b32 %0, %0, %1", "v_alignbit_b32 %0, %0, %0, 27", 1)
+KERNEL2(k2_xor_add3_alt,  "v_xor_b32 %0, %0, %1", "v_add3_u32 %0, %0, %1, %2", 1)
+KERNEL2(k2_xor_xor_alt,   "v_xor_b32 %0, %0, %1", "v_xor_b32 %0, %0, %2", 1)
+KERNEL2(k2_align_add3_alt,"v_alignbit_b32 %0, %0, %0, 27", "v_add3_u32 %0, %0, %1, %2", 1)
+KERNEL2(k2_add_bitop_alt, "v_add_u32 %0, %0, %1", "v_bitop3_b32 %0, %0, %1, %2 bitop3:0xca", 1)
+
 typedef void (*kfn)(uint32_t*, int);
 struct Entry { const char* name; kfn fn; };
 
@@ -103,6 +137,9 @@ int main(int argc, char** argv)
         {"v_sub_u32", k_sub_u32}, {"v_lshrrev_b32", k_lshrrev}, {"v_xnor_b32", k_xnor}, {"v_add_co_u32", k_add_co},
         {"v_cndmask_b32", k_cndmask}, {"v_bfe_u32", k_bfe}, {"v_mul_u32_u24", k_mul_u24}, {"v_mul_lo_u32", k_mul_lo},
         {"v_pk_add_u16", k_pk_add_u16},
+        {"PAIR xor|align grouped", k2_xor_align_grp}, {"PAIR xor|align altern.", k2_xor_align_alt},
+        {"PAIR xor|add3 altern.", k2_xor_add3_alt}, {"PAIR xor|xor altern.", k2_xor_xor_alt},
+        {"PAIR align|add3 altern.", k2_align_add3_alt}, {"PAIR add|bitop3 altern.", k2_add_bitop_alt},
     };
     const int iters = 4000;
     for (auto& e : es) {
