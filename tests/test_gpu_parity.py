@@ -192,6 +192,31 @@ def test_two_queues_on_one_gpu_shard_and_agree(oracle):
         assert h2.stat("launches") >= 2
 
 
+def test_waves_spanning_more_than_4gib_take_the_per_lane_path(hasher):
+    """The LDS-staged kernel addresses a wave's 64 objects as base + 32-bit offset.
+    In an arena beyond 4 GiB an order that puts the first and the last objects in
+    one wave breaks that; such waves must fall back to 64-bit per-lane loads and
+    still give the same ids."""
+    import vit_amd
+    n, L = 1_100_000, 4096                         # 4.58 GB arena
+    hasher.set_option("kernel", 0)
+    b = hasher.synth_arena("blob", 0x5EED0012, 0, n, L)
+    assert b["arena_bytes"] > (1 << 32) + (1 << 28)
+    near = hasher.hash_device(b).copy()            # identity order: every wave is compact
+    order_host = np.empty(n, dtype=np.uint32)
+    order_host[0::2] = np.arange(0, (n + 1) // 2, dtype=np.uint32)          # 0, n-1, 1, n-2, ...
+    order_host[1::2] = np.arange(n - 1, (n + 1) // 2 - 1, -1, dtype=np.uint32)
+    assert len(np.unique(order_host)) == n        # a permutation; only the middle waves stay within 4 GiB
+    order = hasher.alloc(4 * n).upload(order_host)
+    b["digests"].upload(np.zeros(20 * n, dtype=np.uint8))
+    far = hasher.hash_device(b, order=order)
+    assert hasher.device_status() == 0
+    assert (far == near).all()
+    for i in (0, 1, n // 2, n - 2, n - 1):
+        want = hashlib.sha1(b"blob 4096\0" + vit_amd.synth_bytes(0x5EED0012, i, L)).digest()
+        assert far[i].tobytes() == want
+
+
 def test_config2_full_size_1m_x_4k(hasher):
     """BASELINE configs[1] at full size: 1,000,000 x 4 KiB blobs generated on the
     device; every digest checked against hashlib (OpenSSL) on the host copy of the

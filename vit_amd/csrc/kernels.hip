@@ -20,6 +20,8 @@
 #include "kernels.h"
 #include "sha1_device.h"
 
+#include <type_traits>
+
 namespace vit {
 
 typedef __attribute__((address_space(1))) const void* global_cptr;
@@ -33,6 +35,42 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
         v = other > v ? other : v;
     }
     return v;
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t other = (uint32_t)__shfl_xor((int)v, o, 64);
+        v = other < v ? other : v;
+    }
+    return v;
+}
+
+// 64-bit wave reductions; the result is wave-uniform (held in SGPRs).
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint64_t other = (uint64_t)__shfl_xor((unsigned long long)v, o, 64);
+        v = other < v ? other : v;
+    }
+    // readfirstlane returns int: go through uint32_t, or the low half sign-extends into the high one
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint64_t other = (uint64_t)__shfl_xor((unsigned long long)v, o, 64);
+        v = other > v ? other : v;
+    }
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v);
+    return ((uint64_t)hi << 32) | lo;
 }
 
 // Resolve slot -> (object index, offset, block count) with the input checks
@@ -59,6 +97,24 @@ __device__ __forceinline__ Slot resolve_slot(const DeviceBatch& b, uint32_t slot
     return s;
 }
 
+// Plain per-lane loop: the lane loads its own 64-byte blocks (four 16-byte
+// loads, the next block prefetched while the current one is hashed).
+__device__ __forceinline__ void hash_lane_direct(const uint8_t* first_block, uint32_t nb, uint32_t (&h)[5])
+{
+    const uint4* p = reinterpret_cast<const uint4*>(first_block);
+    uint4 q0, q1, q2, q3;
+    if (nb) { q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; }
+    for (uint32_t i = 0; i < nb; ++i) {
+        uint32_t w[16];
+        put_words(w, 0, q0); put_words(w, 4, q1); put_words(w, 8, q2); put_words(w, 12, q3);
+        if (i + 1 < nb) {
+            const uint4* nx = p + 4ull * (i + 1);
+            q0 = nx[0]; q1 = nx[1]; q2 = nx[2]; q3 = nx[3];
+        }
+        sha1_compress(h, w);
+    }
+}
+
 // ---------------------------------------------------------------- LDS-staged --
 // One wave per workgroup; no barrier is needed anywhere because a wave only ever
 // touches its own LDS.
@@ -71,8 +127,10 @@ __device__ __forceinline__ Slot resolve_slot(const DeviceBatch& b, uint32_t slot
 // lane fetches global chunk c.  Reader lane i wants chunk k of object i and
 // finds it at position k ^ sw(i).  sw(i) = (i / (16/LPO)) % LPO makes the 16
 // lanes of every ds_read_b128 lane group hit 16 different 16-byte bank slots.
+// LDS (64*BPS*64 bytes per wave) admits 160 KiB / 8 KiB = 20 waves per CU = 5 per
+// SIMD at BPS = 2; the launch bound asks the register allocator for the same.
 template <int BPS>
-__global__ __launch_bounds__(64) void sha1_lds_kernel(DeviceBatch b)
+__global__ __launch_bounds__(64, BPS == 4 ? 2 : 5) void sha1_lds_kernel(DeviceBatch b)
 {
     constexpr int LPO  = 4 * BPS;        // lanes per object per instruction == instructions per stage
     constexpr int OPI  = 64 / LPO;       // objects per instruction
@@ -97,21 +155,34 @@ __global__ __launch_bounds__(64) void sha1_lds_kernel(DeviceBatch b)
     t_nb[lane]  = my_nb;
     __syncthreads();
 
-    const uint8_t* src[LPO];     // this lane's source pointer for instruction j, stage 0
-    int32_t        lim[LPO];     // instruction j is live for this lane while BPS*t < lim[j]
     const uint32_t p = lane % LPO;
+    const uint32_t my_sw  = (lane / RP) % LPO;
+    const uint32_t my_row = (lane / OPI) * 1024u + (lane % OPI) * ROWB;
+    const uint32_t max_nb = __builtin_amdgcn_readfirstlane(wave_max_u32(my_nb));
+    const uint32_t nst    = (max_nb + BPS - 1) / BPS;
+
+    // Wave-uniform facts: the lowest object offset of the wave is the base of
+    // every fetch, a lane adds a fixed 32-bit offset to it.  That needs the 64
+    // objects within 4 GiB of each other; a wave whose objects are not (only
+    // possible in arenas beyond 4 GiB hashed in a scattering order) takes the
+    // plain per-lane loop instead.  full_stages: stages complete for all 64
+    // lanes (a lane without an object has 0 blocks, so a ragged last wave has none).
+    const uint32_t min_nb  = __builtin_amdgcn_readfirstlane(wave_min_u32(my_nb));
+    const uint64_t min_off = wave_min_u64(my_off), max_off = wave_max_u64(my_off);
+    const bool near = (max_off - min_off) < 0xFFF00000ull;
+    const uint32_t full_stages = min_nb / BPS;
+    const uint8_t* wave_base = b.arena + min_off;
+
+    uint32_t voff[LPO];          // this lane's source for instruction j: wave_base + voff[j] (+ stage offset)
+    int32_t  lim[LPO];           // instruction j is live for this lane while BPS*t < lim[j]
 #pragma unroll
     for (int j = 0; j < LPO; ++j) {
         const uint32_t o  = j * OPI + lane / LPO;          // object (lane id) served
         const uint32_t sw = (o / RP) % LPO;
         const uint32_t c  = p ^ sw;                        // chunk of the row to fetch
-        src[j] = b.arena + t_off[o] + c * 16u;
-        lim[j] = (int32_t)t_nb[o] - (int32_t)(c >> 2);     // chunk c lies in block c/4 of the stage
+        voff[j] = (uint32_t)(t_off[o] - min_off) + c * 16u;
+        lim[j]  = (int32_t)t_nb[o] - (int32_t)(c >> 2);    // chunk c lies in block c/4 of the stage
     }
-    const uint32_t my_sw  = (lane / RP) % LPO;
-    const uint32_t my_row = (lane / OPI) * 1024u + (lane % OPI) * ROWB;
-    const uint32_t max_nb = __builtin_amdgcn_readfirstlane(wave_max_u32(my_nb));
-    const uint32_t nst    = (max_nb + BPS - 1) / BPS;
     // A wave that carries a long object decides when the launch ends; let it win
     // the issue arbitration against the short waves that share its SIMD.
     if (b.prio_blocks && max_nb >= b.prio_blocks) __builtin_amdgcn_s_setprio(3);
@@ -120,17 +191,45 @@ __global__ __launch_bounds__(64) void sha1_lds_kernel(DeviceBatch b)
     uint32_t h[5];
     sha1_init(h);
 
-    auto issue = [&](uint32_t t) {
+    if (!near) {
+        hash_lane_direct(b.arena + my_off, my_nb, h);
+        if (owns) store_digest(b.digests, idx, h);
+        return;
+    }
+
+    // One LDS-DMA load: 16 bytes per live lane from (scalar base + lane offset)
+    // to LDS byte lds_dst + lane*16.  hipcc does not select this scalar-base form
+    // from the builtin, so it is written out; with it a stage costs no vector
+    // instructions for addressing (the scalar unit advances the base).  M0
+    // carries the LDS destination and is saved and restored because the compiler
+    // keeps its own value in it.  The load has no register result; its
+    // completion is awaited by the explicit vmcnt(0) at the top of every stage.
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(lds_ptr)stage;
+    auto dma16 = [](uint32_t lane_off, const uint8_t* base, uint32_t lds_dst) {
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\t"
+                     "s_mov_b32 m0, %3\n\t"
+                     "s_nop 0\n\t"
+                     "global_load_lds_dwordx4 %1, %2\n\t"
+                     "s_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(lane_off), "s"(base), "s"(lds_dst)
+                     : "memory");
+    };
+    // FULL: every lane is live (no predicates at all).
+    auto issue = [&](uint32_t t, auto full_tag) {
+        const uint8_t* sb = wave_base + (uint64_t)t * ROWB;
 #pragma unroll
-        for (int j = 0; j < LPO; ++j) {
-            if ((int32_t)(BPS * t) < lim[j])
-                __builtin_amdgcn_global_load_lds((global_cptr)(src[j] + (uint64_t)t * ROWB),
-                                                 (lds_ptr)(stage + j * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < LPO; ++j)
+            if (decltype(full_tag)::value || (int32_t)(BPS * t) < lim[j])
+                dma16(voff[j], sb, lds_base + (uint32_t)j * 1024u);
     };
 
-    if (nst) issue(0);
-    for (uint32_t t = 0; t < nst; ++t) {
+    // One stage: wait for its DMA, pull this lane's blocks into registers, start
+    // the next stage's DMA, hash.  FULL: this stage and the next are complete for
+    // all 64 lanes.
+    auto stage_body = [&](uint32_t t, auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
         // The DMA writes are tracked by vmcnt only; nothing else orders the
         // ds_reads below behind them.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -141,18 +240,23 @@ __global__ __launch_bounds__(64) void sha1_lds_kernel(DeviceBatch b)
         // All of this stage is in registers before the next stage's DMA may
         // overwrite the buffer.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (t + 1 < nst) issue(t + 1);
+        if (FULL || t + 1 < nst) issue(t + 1, full_tag);
 
 #pragma unroll
         for (int s = 0; s < BPS; ++s) {
-            if (BPS * t + s < my_nb) {
+            if (FULL || BPS * t + s < my_nb) {
                 uint32_t w[16];
                 put_words(w, 0, q[4 * s]);     put_words(w, 4, q[4 * s + 1]);
                 put_words(w, 8, q[4 * s + 2]); put_words(w, 12, q[4 * s + 3]);
                 sha1_compress(h, w);
             }
         }
-    }
+    };
+
+    uint32_t t = 0;
+    if (nst) issue(0, std::false_type());
+    for (; t + 1 < full_stages; ++t) stage_body(t, std::true_type());
+    for (; t < nst; ++t) stage_body(t, std::false_type());
     if (owns) store_digest(b.digests, idx, h);
 }
 
@@ -167,18 +271,7 @@ __global__ __launch_bounds__(256) void sha1_lane_kernel(DeviceBatch b)
 
     uint32_t h[5];
     sha1_init(h);
-    const uint4* p = reinterpret_cast<const uint4*>(b.arena + off);
-    uint4 q0, q1, q2, q3;
-    if (nb) { q0 = p[0]; q1 = p[1]; q2 = p[2]; q3 = p[3]; }
-    for (uint32_t i = 0; i < nb; ++i) {
-        uint32_t w[16];
-        put_words(w, 0, q0); put_words(w, 4, q1); put_words(w, 8, q2); put_words(w, 12, q3);
-        if (i + 1 < nb) {
-            const uint4* nx = p + 4ull * (i + 1);
-            q0 = nx[0]; q1 = nx[1]; q2 = nx[2]; q3 = nx[3];
-        }
-        sha1_compress(h, w);
-    }
+    hash_lane_direct(b.arena + off, nb, h);
     store_digest(b.digests, idx, h);
 }
 
