@@ -34,8 +34,8 @@ OPS_PER_BLOCK = 613         # vector ops per 64-byte SHA-1 block in sha1_device.
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--blobs", type=int, default=N_BLOBS, help="blobs per GPU (default: the BASELINE config)")
     ap.add_argument("--blob-len", type=int, default=BLOB_LEN)
     ap.add_argument("--kernel", choices=["lds", "lane"], default="lds")

@@ -22,12 +22,16 @@ def init(backend=None):
     """Join the process group when WORLD_SIZE > 1.  Returns the torch.distributed
     module, or None for a single process."""
     rank, local_rank, world = env()
-    if world <= 1:
+    # VIT_FORCE_DIST=1 forms the group even for one rank: a way to exercise the RCCL
+    # path (group set-up, device reductions, barrier) on a single-GPU machine.
+    if world <= 1 and not os.environ.get("VIT_FORCE_DIST"):
         return None
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
+    os.environ.setdefault("RANK", str(rank))
+    os.environ.setdefault("WORLD_SIZE", str(world))
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
