@@ -66,12 +66,22 @@ int vit_hasher_device_count(const vit_hasher *h);
  *                         while the GPU batch runs (one SHA-1 stream is serial;
  *                         a lane sustains ~50 MB/s, a host core ~2 GB/s);
  *                         0 = never, every object takes a GPU lane
- *  "host_auto"            1 (default): derive that threshold per call as
- *                         clamp(batch bytes per queue / 1024, 64 KiB, 16 MiB),
- *                         i.e. keep an object on the GPU when its lane time
- *                         hides inside the batch's transfer time
- *  "chunk_bytes"          pinned staging buffer size per queue and stream
- *  "pack_threads"         host threads for packing and for the host lane */
+ *  "host_auto"            1 (default): derive that threshold per call by
+ *                         balancing the two sides: from the longest object
+ *                         down, objects of 64 KiB or more move to the host
+ *                         threads while the host side (its bytes over the
+ *                         threads; its longest object on one core) would
+ *                         still finish before the GPU side (its bytes over
+ *                         pack + PCIe; its longest object on one lane)
+ *  "chunk_bytes"          smallest pinned staging buffer per queue and stream
+ *                         (default 64 MiB); chunks grow with the longest
+ *                         object they may hold, up to 1 GiB
+ *  "chunk_object_multiple" that growth: chunk = longest object x this
+ *                         (default 8192; 0 = fixed chunk_bytes)
+ *  "pack_threads"         host threads for packing and for the host lane
+ *  "trace"                1: vit_hash_objects prints one line per staged
+ *                         chunk to stderr (host and device timestamps of
+ *                         pack, copy, kernel and read-back) */
 int vit_hasher_set_option(vit_hasher *h, const char *name, uint64_t value);
 
 /* Counters since creation: "objects_gpu", "objects_host", "bytes_host",

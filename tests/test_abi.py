@@ -51,10 +51,14 @@ def test_pack_layout_is_what_sha1_compresses(oracle):
     """A packed slot = framed message + FIPS 180-4 padding: hashing its blocks with
     a raw compression loop must give the Git id."""
     import vit_amd
-    lens = list(range(0, 130)) + [4095, 4096, 4097, 65530]
+    lens = list(range(0, 450)) + [4095, 4096, 4097, 65530]
     blobs = [oracle.synth_bytes(21, i, L) for i, L in enumerate(lens)]
-    for t in ("blob", "tree", "commit"):
-        arena, off, nb, used = vit_amd.pack_arena(t, blobs, threads=3)
+    room = np.zeros(sum(len(b) + 128 for b in blobs) + 128, dtype=np.uint8)
+    skip = (-room.ctypes.data) % 64
+    # an aligned arena takes the packer's streaming-store path, one off by 16 bytes its plain path
+    for t, given in (("blob", None), ("tree", None), ("commit", None), ("blob", room[skip + 16:])):
+        arena, off, nb, used = vit_amd.pack_arena(t, blobs, arena=given, threads=3)
+        assert (arena.ctypes.data % 64 == 0) == (given is None)
         assert used == int(nb.astype(np.uint64).sum()) * 64
         assert (off % 64 == 0).all()
         assert (off[1:] == off[:-1] + nb[:-1].astype(np.uint64) * 64).all()

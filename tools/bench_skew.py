@@ -6,6 +6,10 @@
   skew    config 5: a few multi-GiB blobs plus 1,000,000 tiny ones (0..256 B) from host memory
           through vit_hash_blobs: the giants go to host threads, the rest to the GPU, concurrently.
 
+  c4      all of config 4 through one GPU: 10,000,000 blobs of that distribution (about 150 GB),
+          streamed in slices from host memory through vit_hash_blobs (pack + H2D + kernel + D2H,
+          long objects on host threads).  Hashing only: nothing is deflated or stored.
+
 Measurement tool; ids are spot-checked against hashlib.  Prints one JSON line.
 """
 import argparse
@@ -88,6 +92,90 @@ def skew(a):
     print(json.dumps(out), flush=True)
 
 
+def c4(a):
+    from concurrent.futures import ThreadPoolExecutor
+    from vit_amd import _abi
+    lib = _abi.load()
+    h = vit_amd.Hasher((0,))
+    seed = 0x5EED0004
+    per = (a.n + a.slices - 1) // a.slices
+    threads = min(os.cpu_count() or 1, 16)
+    out = {"workload": "c4", "n": a.n, "slices": a.slices, "fill_threads": threads}
+    summary = np.zeros(20, dtype=np.uint8)
+    hash_s = fill_s = 0.0
+    payload = checked = 0
+    per_slice = []
+    g0, h0, b0 = h.stat("objects_gpu"), h.stat("objects_host"), h.stat("bytes_host")
+    for k in range(a.slices):
+        first, n = k * per, min(per, a.n - k * per)
+        if n <= 0:
+            break
+        rng = np.random.default_rng(seed + 1000 * k)              # sizes: one stream per slice
+        sizes = np.exp(rng.normal(np.log(4500.0), 1.55, n))
+        sizes = np.minimum(sizes * (15000.0 / sizes.mean()), a.clip).astype(np.uint64)
+        if a.uniform_bytes is not None:
+            sizes[:] = a.uniform_bytes
+        offs = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum(sizes, out=offs[1:])
+        buf = np.empty(int(offs[-1]) + 1, dtype=np.uint8)
+        base = buf.ctypes.data
+        t0 = time.perf_counter()
+
+        def fill(r):
+            for i in range(r[0], r[1]):
+                lib.vit_synth_bytes(seed, first + i, base + int(offs[i]), int(sizes[i]))
+        step = (n + 8 * threads - 1) // (8 * threads)
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(fill, [(i, min(i + step, n)) for i in range(0, n, step)]))
+        fill_s += time.perf_counter() - t0
+        ptrs = (offs[:n] + np.uint64(base)).astype(np.uint64)
+        dig = np.zeros((n, 20), dtype=np.uint8)
+        if a.trace:                                    # one slice twice, the second with the library's chunk timeline
+            lib.vit_hash_blobs(h.handle, ptrs.ctypes.data, sizes.ctypes.data, n, dig.ctypes.data)
+            h.set_option("trace", 1)
+            h._check(lib.vit_hash_blobs(h.handle, ptrs.ctypes.data, sizes.ctypes.data, n, dig.ctypes.data))
+            return
+        if a.sweep:                                    # one slice, several pipeline settings, then stop
+            res = []
+            for mult, thr in [(8192, None), (8192, None), (4096, None), (16384, None), (8192, None), (4096, None),
+                              (16384, None), (2048, None), (8192, 256 << 10), (8192, 32 << 10)]:
+                chunk_mb = 64
+                h.set_option("chunk_object_multiple", mult)
+                if thr is None:
+                    h.set_option("host_auto", 1)
+                else:
+                    h.set_option("host_threshold_bytes", thr)
+                t0 = time.perf_counter()
+                h._check(lib.vit_hash_blobs(h.handle, ptrs.ctypes.data, sizes.ctypes.data, n, dig.ctypes.data))
+                dt = time.perf_counter() - t0
+                res.append({"mult": mult, "host_threshold": thr, "s": round(dt, 3),
+                            "GBps": round(int(offs[-1]) / dt / 1e9, 1), "pack_ms": round(h.stat("last_pack_ns") / 1e6, 1),
+                            "thr_used": h.stat("last_host_threshold")})
+                print(json.dumps(res[-1]), flush=True)
+            return
+        t0 = time.perf_counter()
+        h._check(lib.vit_hash_blobs(h.handle, ptrs.ctypes.data, sizes.ctypes.data, n, dig.ctypes.data))
+        dt = time.perf_counter() - t0
+        hash_s += dt
+        payload += int(offs[-1])
+        per_slice.append(round(dt, 3))
+        summary ^= np.bitwise_xor.reduce(dig, axis=0)
+        pick = set(np.random.default_rng(k).integers(0, n, 200).tolist()) | {0, n - 1, int(np.argmax(sizes))}
+        for i in pick:
+            hh = hashlib.sha1(b"blob %d\0" % int(sizes[i]))
+            hh.update(memoryview(buf[int(offs[i]):int(offs[i + 1])]))
+            assert dig[i].tobytes() == hh.digest(), (k, i)
+        checked += len(pick)
+        del buf
+    out.update({"payload_bytes": payload, "hash_seconds": round(hash_s, 3), "fill_seconds": round(fill_s, 1),
+                "GBps": round(payload / hash_s / 1e9, 2), "objects_per_s": round(a.n / hash_s, 1),
+                "per_slice_seconds": per_slice, "objects_gpu": h.stat("objects_gpu") - g0,
+                "objects_host": h.stat("objects_host") - h0, "bytes_host": h.stat("bytes_host") - b0,
+                "last_host_threshold": h.stat("last_host_threshold"), "ids_checked_vs_hashlib": checked,
+                "xor_of_ids": summary.tobytes().hex()})
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -99,8 +187,15 @@ def main():
     s.add_argument("--giants", type=int, default=4)
     s.add_argument("--giant-bytes", type=int, default=2 << 30)
     s.add_argument("--tiny", type=int, default=1_000_000)
+    c = sub.add_parser("c4")
+    c.add_argument("--n", type=int, default=10_000_000)
+    c.add_argument("--slices", type=int, default=10)
+    c.add_argument("--clip", type=int, default=32 << 20)
+    c.add_argument("--sweep", action="store_true", help="first slice only, under several chunk sizes / host thresholds")
+    c.add_argument("--uniform-bytes", type=int, default=None, help="every blob this long instead of the distribution")
+    c.add_argument("--trace", action="store_true", help="first slice only, print the per-chunk timeline")
     a = ap.parse_args()
-    mixed(a) if a.cmd == "mixed" else skew(a)
+    {"mixed": mixed, "skew": skew, "c4": c4}[a.cmd](a)
 
 
 if __name__ == "__main__":

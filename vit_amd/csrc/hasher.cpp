@@ -45,7 +45,9 @@ struct Staging {
     uint64_t* d_off = nullptr;    uint32_t* d_nb = nullptr;  uint32_t* d_order = nullptr;  uint8_t* d_dig = nullptr;
     uint64_t  m_cap = 0;                                  // objects the meta buffers hold
     hipEvent_t done = nullptr;
-    bool in_flight = false;
+    hipEvent_t mark[4] = {nullptr, nullptr, nullptr, nullptr};   // trace only: before copy, after copy, after kernel, after read-back
+    double host_ms[4] = {0, 0, 0, 0};                            // trace only: submit begin, previous chunk retired, packed, queued
+    bool in_flight = false, traced = false;
     std::vector<uint64_t> obj;                            // caller indices of the chunk in flight
 };
 
@@ -55,6 +57,8 @@ struct Queue {
     uint32_t* d_status = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     std::vector<hipEvent_t> timing;                       // pool for vit_time_hash_device
+    std::string trace_log;                                // per-chunk timeline of the last call, when tracing
+    clk::time_point trace_t0;
     Staging st[3];
     std::string err;                                      // set by the queue's worker thread
 };
@@ -70,6 +74,8 @@ struct vit_hasher {
     int host_policy = 1;
     uint64_t host_threshold = 0;
     uint64_t chunk_bytes = 64ull << 20;
+    uint64_t chunk_object_multiple = 8192;
+    bool trace = false;
     int pack_threads = 8;
     std::atomic<uint64_t> objects_gpu{0}, objects_host{0}, bytes_host{0}, blocks_gpu{0}, bytes_h2d{0}, launches{0};
     uint64_t last_host_threshold = 0;
@@ -174,6 +180,7 @@ void free_staging(Staging& s)
         (void)hipFree(s.d_off); (void)hipFree(s.d_nb); (void)hipFree(s.d_order); (void)hipFree(s.d_dig);
     }
     if (s.done) (void)hipEventDestroy(s.done);
+    for (hipEvent_t m : s.mark) if (m) (void)hipEventDestroy(m);
     s = Staging();
 }
 
@@ -198,6 +205,17 @@ int retire(Queue& q, Staging& s, uint8_t* digests)
     HIP_TRYQ(q, hipEventSynchronize(s.done));
     for (size_t i = 0; i < s.obj.size(); ++i) std::memcpy(digests + s.obj[i] * 20, s.h_dig + i * 20, 20);
     s.in_flight = false;
+    if (s.traced) {
+        float g[4] = {0, 0, 0, 0};
+        for (int k = 0; k < 4; ++k) HIP_TRYQ(q, hipEventElapsedTime(&g[k], q.ev_a, s.mark[k]));
+        char line[256];
+        std::snprintf(line, sizeof line,
+                      "set %d objs %8zu | host ms: begin %8.2f retired-prev %8.2f packed %8.2f queued %8.2f collected %8.2f"
+                      " | gpu ms: copy %8.2f..%8.2f kernel ..%8.2f read-back ..%8.2f\n",
+                      int(&s - q.st), s.obj.size(), s.host_ms[0], s.host_ms[1], s.host_ms[2], s.host_ms[3],
+                      double(ns_since(q.trace_t0)) * 1e-6, g[0], g[1], g[2], g[3]);
+        q.trace_log += line;
+    }
     return VIT_OK;
 }
 
@@ -215,8 +233,15 @@ int submit_chunk(Queue& q, const Job& job, Staging& s, hipStream_t stream, const
                  uint64_t* pack_ns)
 {
     vit_hasher* h = job.h;
+    const double begin_ms = double(ns_since(q.trace_t0)) * 1e-6;
     int rc = retire(q, s, job.digests);
     if (rc) return rc;
+    if (h->trace) {
+        for (hipEvent_t& m : s.mark) if (!m) HIP_TRYQ(q, hipEventCreate(&m));
+        s.host_ms[0] = begin_ms;
+        s.host_ms[1] = double(ns_since(q.trace_t0)) * 1e-6;
+    }
+    const bool trace = s.traced = h->trace && s.mark[3];
     uint64_t blocks = 0;
     for (uint64_t i = 0; i < cnt; ++i) blocks += job.nb[idx[i]];
     const uint64_t bytes = blocks * 64;
@@ -237,19 +262,24 @@ int submit_chunk(Queue& q, const Job& job, Staging& s, hipStream_t stream, const
             const uint64_t o = idx[i];
             vit::pack_one(job.type, job.tl, job.data[o], job.len[o], s.h_arena + s.h_off[i], s.h_nb[i]);
         }
+        vit::pack_fence();
     });
     const bool binned = vit::bin_order(s.h_nb, cnt, s.h_order);
     *pack_ns += ns_since(t0);
 
+    if (trace) { s.host_ms[2] = double(ns_since(q.trace_t0)) * 1e-6; HIP_TRYQ(q, hipEventRecord(s.mark[0], stream)); }
     HIP_TRYQ(q, hipMemcpyAsync(s.d_arena, s.h_arena, bytes, hipMemcpyHostToDevice, stream));
     HIP_TRYQ(q, hipMemcpyAsync(s.d_off, s.h_off, cnt * 8, hipMemcpyHostToDevice, stream));
     HIP_TRYQ(q, hipMemcpyAsync(s.d_nb, s.h_nb, cnt * 4, hipMemcpyHostToDevice, stream));
     if (binned) HIP_TRYQ(q, hipMemcpyAsync(s.d_order, s.h_order, cnt * 4, hipMemcpyHostToDevice, stream));
+    if (trace) HIP_TRYQ(q, hipEventRecord(s.mark[1], stream));
     HIP_TRYQ(q, vit::launch_sha1(vit::KernelVariant(h->kernel),
                                  make_batch(q, s.d_arena, bytes, s.d_off, s.d_nb, binned ? s.d_order : nullptr, cnt,
                                             s.d_dig),
                                  stream));
+    if (trace) HIP_TRYQ(q, hipEventRecord(s.mark[2], stream));
     HIP_TRYQ(q, hipMemcpyAsync(s.h_dig, s.d_dig, cnt * 20, hipMemcpyDeviceToHost, stream));
+    if (trace) { HIP_TRYQ(q, hipEventRecord(s.mark[3], stream)); s.host_ms[3] = double(ns_since(q.trace_t0)) * 1e-6; }
     HIP_TRYQ(q, hipEventRecord(s.done, stream));
     s.in_flight = true;
     h->objects_gpu += cnt; h->blocks_gpu += blocks; h->bytes_h2d += bytes + cnt * 16; ++h->launches;
@@ -267,6 +297,9 @@ int run_queue(Queue& q, const Job& job, const std::vector<uint64_t>& mine, uint6
 {
     vit_hasher* h = job.h;
     HIP_TRYQ(q, hipSetDevice(q.device));
+    q.trace_t0 = clk::now();
+    q.trace_log.clear();
+    if (h->trace) HIP_TRYQ(q, hipEventRecord(q.ev_a, q.stream[0]));
     std::vector<uint64_t> longs, rest;
     for (uint64_t i : mine) (job.nb[i] >= kLongBlocks ? longs : rest).push_back(i);
     std::stable_sort(longs.begin(), longs.end(), [&](uint64_t a, uint64_t b) { return job.nb[a] > job.nb[b]; });
@@ -283,24 +316,43 @@ int run_queue(Queue& q, const Job& job, const std::vector<uint64_t>& mine, uint6
         }
         return out;
     };
-    const auto long_chunks = cut(longs, h->chunk_bytes * 4);
-    const auto rest_chunks = cut(rest, h->chunk_bytes);
+    // A chunk's kernel lasts at least as long as its longest object on one lane
+    // (45 MB/s; 1.5 ms for 64 KiB), while its transfer runs about 1000 times
+    // faster per byte, and measured transfers slow down while another chunk's
+    // kernel is running.  Chunks therefore grow with the longest object they may
+    // hold, to chunk_object_multiple (8192) times its size: 512 MiB for 64 KiB
+    // objects gave twice the throughput of 64 MiB on a skewed 15 GB batch.
+    // Bounds: [configured chunk size, 1 GiB], and at most 1/8 of the batch so
+    // that packing, copying and hashing still overlap.
+    uint64_t rest_bytes = 0, rest_longest = 0;
+    for (uint64_t i : rest) {
+        rest_bytes += uint64_t(job.nb[i]) * 64;
+        rest_longest = std::max<uint64_t>(rest_longest, job.nb[i]);
+    }
+    uint64_t chunk = std::min<uint64_t>(rest_longest * 64 * h->chunk_object_multiple, rest_bytes / 8);
+    chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, h->chunk_bytes), 1ull << 30);
+    const auto long_chunks = cut(longs, std::max<uint64_t>(chunk, 256ull << 20));
+    const auto rest_chunks = cut(rest, chunk);
 
+    // Long chunks go first and then whenever their staging set has drained, so
+    // that their lane-bound kernels run beside the short objects' chunks and
+    // not after them.
     int rc;
-    if (!long_chunks.empty() &&
-        (rc = submit_chunk(q, job, q.st[2], q.stream[2], longs.data() + long_chunks[0].first,
-                           long_chunks[0].second - long_chunks[0].first, pack_ns)))
-        return rc;
+    size_t next_long = 0;
+    auto submit_long = [&]() -> int {
+        const auto& c = long_chunks[next_long++];
+        return submit_chunk(q, job, q.st[2], q.stream[2], longs.data() + c.first, c.second - c.first, pack_ns);
+    };
+    if (!long_chunks.empty() && (rc = submit_long())) return rc;
     int turn = 0;
     for (const auto& c : rest_chunks) {
         if ((rc = submit_chunk(q, job, q.st[turn], q.stream[turn], rest.data() + c.first, c.second - c.first, pack_ns)))
             return rc;
         turn ^= 1;
+        if (next_long < long_chunks.size() && hipEventQuery(q.st[2].done) == hipSuccess && (rc = submit_long())) return rc;
     }
-    for (size_t k = 1; k < long_chunks.size(); ++k)
-        if ((rc = submit_chunk(q, job, q.st[2], q.stream[2], longs.data() + long_chunks[k].first,
-                               long_chunks[k].second - long_chunks[k].first, pack_ns)))
-            return rc;
+    while (next_long < long_chunks.size())
+        if ((rc = submit_long())) return rc;
     for (Staging& s : q.st)
         if ((rc = retire(q, s, job.digests))) return rc;
     return VIT_OK;
@@ -419,6 +471,8 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     } else if (k == "host_threshold_bytes") { h->host_threshold = value; h->host_policy = value ? 2 : 0; }
     else if (k == "host_auto") { h->host_policy = value ? 1 : (h->host_threshold ? 2 : 0); }
     else if (k == "chunk_bytes") h->chunk_bytes = value < (1u << 20) ? (1u << 20) : value;
+    else if (k == "chunk_object_multiple") h->chunk_object_multiple = value;
+    else if (k == "trace") h->trace = value != 0;
     else if (k == "pack_threads") h->pack_threads = value < 1 ? 1 : int(value > 256 ? 256 : value);
     else return fail(h, VIT_ERR_ARG, "unknown option '%s'", name);
     return VIT_OK;
@@ -455,19 +509,36 @@ int vit_hash_objects(vit_hasher* h, const char* type, const uint8_t* const* data
     const auto t0 = clk::now();
     VIT_NOEXCEPT_BEGIN
 
-    // One SHA-1 stream is serial: a lane sustains ~50 MB/s, a host core with SHA
-    // extensions ~2 GB/s, while a whole batch moves through pack + PCIe at tens
-    // of GB/s per GPU.  An object is therefore worth a lane only if its lane time
-    // hides inside the batch: auto policy keeps objects up to
-    // (batch bytes per queue) / 1024 on the GPU, within [64 KiB, 16 MiB];
-    // larger ones are hashed on host threads while the GPU batch runs.
+    // One SHA-1 stream is serial: a lane sustains about 45 MB/s and a host core
+    // with SHA extensions about 1.8 GB/s, while a whole batch moves through
+    // pack + PCIe at about 40 GB/s per GPU.  The auto policy balances the two
+    // sides: starting from the longest object, an object of 64 KiB or more
+    // moves to the host threads as long as the host side (its bytes over the
+    // threads, never less than its longest object on one core) still finishes
+    // before the GPU side would with the object on it (transfer time of its
+    // bytes, never less than its longest object on one lane).  Packing is
+    // memory-bound and light, so the same threads carry both.
     uint64_t threshold = 0;
     if (h->host_policy == 2) threshold = h->host_threshold;
     else if (h->host_policy == 1) {
+        constexpr double kLaneRate = 45e6, kQueueRate = 40e9;
+        const double core_rate = vit::HostSha1::accelerated() ? 1.8e9 : 0.45e9;
+        const double host_rate = core_rate * double(h->pack_threads);
         uint64_t total = 0;
-        for (uint64_t i = 0; i < n; ++i) total += len[i];
-        threshold = total / h->queues.size() / 1024;
-        threshold = std::min<uint64_t>(std::max<uint64_t>(threshold, 64u << 10), 16u << 20);
+        std::vector<uint64_t> cand;
+        for (uint64_t i = 0; i < n; ++i) {
+            total += len[i];
+            if (len[i] >= (64u << 10)) cand.push_back(len[i]);
+        }
+        std::sort(cand.begin(), cand.end(), std::greater<uint64_t>());
+        double gpu_bytes = double(total), host_bytes = 0;
+        for (uint64_t L : cand) {
+            const double gpu_time = std::max(gpu_bytes / (kQueueRate * double(h->queues.size())), double(L) / kLaneRate);
+            const double host_time = std::max((host_bytes + double(L)) / host_rate, double(cand[0]) / core_rate);
+            if (host_time >= gpu_time) break;
+            gpu_bytes -= double(L); host_bytes += double(L);
+            threshold = L - 1;
+        }
     }
     h->last_host_threshold = threshold;
 
@@ -522,6 +593,10 @@ int vit_hash_objects(vit_hasher* h, const char* type, const uint8_t* const* data
     h->last_pack_ns = 0;
     for (uint64_t p : pack_ns) h->last_pack_ns = std::max(h->last_pack_ns, p);
     h->last_total_ns = ns_since(t0);
+    if (h->trace)
+        for (size_t k = 0; k < h->queues.size(); ++k)
+            std::fprintf(stderr, "[vit trace] queue %zu, %.2f ms in all, %zu objects on host threads\n%s", k,
+                         double(h->last_total_ns) * 1e-6, host_idx.size(), h->queues[k].trace_log.c_str());
     for (size_t k = 0; k < rcs.size(); ++k)
         if (rcs[k] != VIT_OK) return fail(h, rcs[k], "device queue %zu: %s", k, h->queues[k].err.c_str());
     for (size_t k = 0; k < h->queues.size(); ++k) {

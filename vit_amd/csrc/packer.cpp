@@ -12,6 +12,7 @@
 #include "packer.h"
 
 #include <cstring>
+#include <emmintrin.h>
 #include <numeric>
 
 namespace vit {
@@ -37,7 +38,8 @@ uint32_t write_header(const char* type, uint32_t tl, uint64_t len, uint8_t* out)
     return tl + 1 + nd + 1;
 }
 
-void pack_one(const char* type, uint32_t tl, const uint8_t* data, uint64_t len, uint8_t* slot, uint64_t nblocks)
+// Cached stores for one short slot (a few blocks): simple and rarely hot.
+static void pack_small(const char* type, uint32_t tl, const uint8_t* data, uint64_t len, uint8_t* slot, uint64_t nblocks)
 {
     const uint32_t hl = write_header(type, tl, len, slot);
     if (len) std::memcpy(slot + hl, data, size_t(len));
@@ -47,6 +49,41 @@ void pack_one(const char* type, uint32_t tl, const uint8_t* data, uint64_t len, 
     const uint64_t bits = msg * 8;
     for (int i = 0; i < 8; ++i) slot[total - 8 + i] = uint8_t(bits >> (56 - 8 * i));
 }
+
+static inline void stream64(uint8_t* dst, const uint8_t* src)
+{
+    for (int k = 0; k < 4; ++k)
+        _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + k, _mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + k));
+}
+
+// The staging arena is written once and next read by the copy engine, never by
+// this core again: non-temporal stores skip the read-for-ownership of every
+// destination line and keep the source data from being evicted by it, which
+// matters once packing, the copy engine and the host hash lanes share the
+// memory controllers.  The slot is 64-byte aligned; the header shifts the
+// content by hl bytes, so loads are unaligned and stores aligned.
+void pack_one(const char* type, uint32_t tl, const uint8_t* data, uint64_t len, uint8_t* slot, uint64_t nblocks)
+{
+    if (nblocks < 4 || (reinterpret_cast<uintptr_t>(slot) & 63)) { pack_small(type, tl, data, len, slot, nblocks); return; }
+    alignas(64) uint8_t edge[128];
+    const uint32_t hl = write_header(type, tl, len, edge);       // hl <= 31, len >= 64*3 - 40 here
+    const uint64_t msg = hl + len, total = nblocks * 64;
+    std::memcpy(edge + hl, data, 64 - hl);
+    stream64(slot, edge);
+    uint64_t off = 64;
+    for (; off + 64 <= msg; off += 64) stream64(slot + off, data + (off - hl));   // message offset off = content offset off - hl
+    // What is left: under 64 content bytes, the 0x80, zeros and the bit length, in one or two blocks.
+    const uint64_t left = total - off;                           // 64 or 128
+    std::memset(edge, 0, sizeof edge);
+    if (msg > off) std::memcpy(edge, data + (off - hl), size_t(msg - off));
+    edge[msg - off] = 0x80;
+    const uint64_t bits = msg * 8;
+    for (int i = 0; i < 8; ++i) edge[left - 8 + i] = uint8_t(bits >> (56 - 8 * i));
+    stream64(slot + off, edge);
+    if (left == 128) stream64(slot + off + 64, edge + 64);
+}
+
+void pack_fence() { _mm_sfence(); }
 
 // LSD radix sort of indices by block count, descending, stable.
 bool bin_order(const uint32_t* nblocks, uint64_t n, uint32_t* order)
@@ -129,6 +166,7 @@ int vit_arena_pack(const char* type, const uint8_t* const* data, const uint64_t*
     if (total < (8u << 20)) threads = 1;
     vit::parallel_ranges(n, threads, prefix.data(), [&](int, uint64_t b, uint64_t e) {
         for (uint64_t i = b; i < e; ++i) vit::pack_one(type, tl, data[i], len[i], base + offsets[i], nblocks[i]);
+        vit::pack_fence();
     });
     return VIT_OK;
     } catch (const std::exception&) { return VIT_ERR_NOMEM; }     // nothing propagates out of the C ABI

@@ -11,6 +11,9 @@ uint32_t write_header(const char* type, uint32_t type_len, uint64_t len, uint8_t
 // Header + content + SHA-1 padding into a slot of nblocks*64 bytes.
 void pack_one(const char* type, uint32_t type_len, const uint8_t* data, uint64_t len, uint8_t* slot,
               uint64_t nblocks);
+// pack_one writes with non-temporal stores: each packing thread calls this once
+// after its last slot, before another agent (a copy engine) reads the arena.
+void pack_fence();
 // order[] = indices by block count, longest first, stable; false if all equal.
 bool bin_order(const uint32_t* nblocks, uint64_t n, uint32_t* order);
 

@@ -58,8 +58,10 @@ def pack_arena(type_, blobs, arena=None, threads=4):
     keep, ptrs, lens = _as_ptr_arrays(blobs)
     n = len(blobs)
     need = sum(int(lib.vit_object_blocks(type_.encode(), int(l))) for l in lens[:n]) * 64
-    if arena is None:
-        arena = np.zeros(max(need, 64), dtype=np.uint8)
+    if arena is None:                       # 64-byte aligned, as the pinned staging arenas are
+        raw = np.zeros(max(need, 64) + 64, dtype=np.uint8)
+        skip = (-raw.ctypes.data) % 64
+        arena = raw[skip:skip + max(need, 64)]
     offsets = np.zeros(max(n, 1), dtype=np.uint64)
     nblocks = np.zeros(max(n, 1), dtype=np.uint32)
     used = C.c_uint64(0)
