@@ -121,7 +121,8 @@ def main():
     h.set_option("kernel", vit_amd.KERNEL_LDS if args.kernel == "lds" else vit_amd.KERNEL_LANE)
 
     n, L = args.blobs, args.blob_len
-    batch = h.synth_arena("blob", SEED, vdist.weak_first_index(rank, n), n, L)   # rank r: blobs [r*n, (r+1)*n)
+    # rank r: blobs [r*n, (r+1)*n); slots start on 128-byte boundaries (the L2 line), see vit_arena_pack_aligned
+    batch = h.synth_arena("blob", SEED, vdist.weak_first_index(rank, n), n, L, slot_align=128)
     hdr = vit_amd.header_len("blob", L)
     nb = vit_amd.object_blocks("blob", L)
 

@@ -72,6 +72,27 @@ def test_pack_layout_is_what_sha1_compresses(oracle):
             assert int(nb[i]) == (len(framed) + 9 + 63) // 64
 
 
+def test_pack_aligned_starts_slots_on_the_boundary(oracle):
+    """slot_align = 128: same slots, each starting on a 128-byte boundary, gaps untouched."""
+    import vit_amd
+    lens = [0, 1, 55, 56, 119, 120, 200, 4096, 4097, 64 * 7 - 15]
+    blobs = [oracle.synth_bytes(22, i, L) for i, L in enumerate(lens)]
+    a64, off64, nb64, used64 = vit_amd.pack_arena("blob", blobs)
+    room = np.full(used64 * 2 + 256, 0xEE, dtype=np.uint8)
+    skip = (-room.ctypes.data) % 128
+    a, off, nb, used = vit_amd.pack_arena("blob", blobs, arena=room[skip:], slot_align=128)
+    assert (nb == nb64).all() and (off % 128 == 0).all()
+    assert used == int(off[-1]) + int(nb[-1]) * 64
+    for i in range(len(blobs)):
+        want = a64[int(off64[i]):int(off64[i]) + int(nb64[i]) * 64]
+        assert (a[int(off[i]):int(off[i]) + int(nb[i]) * 64] == want).all()
+        end = int(off[i]) + int(nb[i]) * 64
+        nxt = int(off[i + 1]) if i + 1 < len(blobs) else end
+        assert nxt - end in (0, 64) and (a[end:nxt] == 0xEE).all()
+    with pytest.raises(vit_amd.VitError):
+        vit_amd.pack_arena("blob", blobs, slot_align=96)
+
+
 def test_pack_rejects_small_arena_and_bad_args(lib):
     import vit_amd
     blobs = [b"x" * 100]

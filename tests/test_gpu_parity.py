@@ -96,6 +96,27 @@ def test_skewed_batch_with_large_objects(hasher, oracle, kernel):
     assert hasher.stat("objects_host") - h0 == 3
 
 
+def test_slots_aligned_to_128_bytes_hash_the_same(hasher, oracle):
+    """A resident arena may start its slots on 128-byte boundaries (the gap after an
+    odd block count is never read as data): same ids from a packed host arena and
+    from the device generator."""
+    import vit_amd
+    lens = [0, 1, 55, 56, 119, 120, 200, 4096, 4097, 9000] + [(i * 53) % 3000 for i in range(700)]
+    blobs = [oracle.synth_bytes(48, i, L) for i, L in enumerate(lens)]
+    want = ids_of(oracle, "blob", blobs)
+    arena, off, nb, used = vit_amd.pack_arena("blob", blobs, slot_align=128)
+    assert (off % 128 == 0).all()
+    assert_same(hasher.hash_arena(arena, off, nb, arena_bytes=used), want, lens)
+    n = 5000
+    b64 = hasher.synth_arena("blob", 77, 3, n, 4096)
+    b128 = hasher.synth_arena("blob", 77, 3, n, 4096, slot_align=128)
+    assert b128["arena_bytes"] == n * 4224 and b64["arena_bytes"] == n * 4160
+    d64, d128 = hasher.hash_device(b64), hasher.hash_device(b128)
+    assert (d64 == d128).all()
+    assert d128[17].tobytes() == oracle.object_id("blob", oracle.synth_bytes(77, 3 + 17, 4096))
+    assert hasher.device_status(0) == 0
+
+
 def test_chunked_pipeline_matches_single_chunk(hasher, oracle):
     """Force many small staging chunks so both pinned buffers cycle several times."""
     lens = [(i * 37) % 5000 for i in range(3000)]

@@ -35,6 +35,8 @@ SIGNATURES = {
     "vit_arena_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "vit_arena_free": (C.c_int, [vp, vp]),
     "vit_arena_pack": (C.c_int, [C.c_char_p, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, u64p, C.c_int]),
+    "vit_arena_pack_aligned": (C.c_int, [C.c_char_p, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, u64p, C.c_int,
+                                         C.c_uint32]),
     "vit_bin_order": (C.c_int, [vp, C.c_uint64, vp]),
     "vit_shard_plan": (C.c_int, [vp, C.c_uint64, C.c_int, vp]),
     "vit_hash_arena": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp, C.c_uint64, vp]),

@@ -145,22 +145,33 @@ int vit_arena_pack(const char* type, const uint8_t* const* data, const uint64_t*
                    void* arena, uint64_t arena_bytes, uint64_t* offsets, uint32_t* nblocks,
                    uint64_t* used_bytes, int threads)
 {
+    return vit_arena_pack_aligned(type, data, len, n, arena, arena_bytes, offsets, nblocks, used_bytes, threads, 64);
+}
+
+int vit_arena_pack_aligned(const char* type, const uint8_t* const* data, const uint64_t* len, uint64_t n,
+                           void* arena, uint64_t arena_bytes, uint64_t* offsets, uint32_t* nblocks,
+                           uint64_t* used_bytes, int threads, uint32_t slot_align)
+{
     const uint32_t tl = vit::type_len_checked(type);
     if (!tl || (n && (!data || !len || !arena || !offsets || !nblocks))) return VIT_ERR_ARG;
+    if (slot_align < 64 || (slot_align & (slot_align - 1))) return VIT_ERR_ARG;
     try {
-    std::vector<uint64_t> prefix(n + 1, 0);
+    const uint64_t per = slot_align / 64;                   // slot starts, in blocks
+    std::vector<uint64_t> prefix(n + 1, 0);                 // prefix[i] = start of slot i, in blocks
+    std::vector<uint32_t> nb_of(n);
     for (uint64_t i = 0; i < n; ++i) {
         if (len[i] && !data[i]) return VIT_ERR_ARG;
         const uint64_t nb = (tl + 1 + vit::decimal_digits(len[i]) + 1 + len[i] + 9 + 63) / 64;
         if (nb > 0xFFFFFFFFull) return VIT_ERR_RANGE;
-        prefix[i + 1] = prefix[i] + nb;
+        nb_of[i] = uint32_t(nb);
+        prefix[i + 1] = (prefix[i] + nb + per - 1) / per * per;
     }
-    const uint64_t total = prefix[n] * 64;
+    const uint64_t total = n ? (prefix[n - 1] + nb_of[n - 1]) * 64 : 0;
     if (used_bytes) *used_bytes = total;
     if (total > arena_bytes) return VIT_ERR_RANGE;
     for (uint64_t i = 0; i < n; ++i) {
         offsets[i] = prefix[i] * 64;
-        nblocks[i] = uint32_t(prefix[i + 1] - prefix[i]);
+        nblocks[i] = nb_of[i];
     }
     uint8_t* base = static_cast<uint8_t*>(arena);
     if (total < (8u << 20)) threads = 1;

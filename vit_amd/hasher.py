@@ -52,12 +52,13 @@ def _as_ptr_arrays(blobs):
     return keep, ptrs, lens
 
 
-def pack_arena(type_, blobs, arena=None, threads=4):
-    """Host-only packing (vit_arena_pack).  Returns (arena, offsets, nblocks, used)."""
+def pack_arena(type_, blobs, arena=None, threads=4, slot_align=64):
+    """Host-only packing (vit_arena_pack_aligned).  Returns (arena, offsets, nblocks, used)."""
     lib = _abi.load()
     keep, ptrs, lens = _as_ptr_arrays(blobs)
     n = len(blobs)
-    need = sum(int(lib.vit_object_blocks(type_.encode(), int(l))) for l in lens[:n]) * 64
+    need = sum((int(lib.vit_object_blocks(type_.encode(), int(l))) * 64 + slot_align - 1) // slot_align * slot_align
+               for l in lens[:n])
     if arena is None:                       # 64-byte aligned, as the pinned staging arenas are
         raw = np.zeros(max(need, 64) + 64, dtype=np.uint8)
         skip = (-raw.ctypes.data) % 64
@@ -65,10 +66,10 @@ def pack_arena(type_, blobs, arena=None, threads=4):
     offsets = np.zeros(max(n, 1), dtype=np.uint64)
     nblocks = np.zeros(max(n, 1), dtype=np.uint32)
     used = C.c_uint64(0)
-    rc = lib.vit_arena_pack(type_.encode(), ptrs, lens.ctypes.data, n, arena.ctypes.data, arena.size,
-                            offsets.ctypes.data, nblocks.ctypes.data, C.byref(used), threads)
+    rc = lib.vit_arena_pack_aligned(type_.encode(), ptrs, lens.ctypes.data, n, arena.ctypes.data, arena.size,
+                                    offsets.ctypes.data, nblocks.ctypes.data, C.byref(used), threads, slot_align)
     if rc != 0:
-        raise VitError(rc, "vit_arena_pack")
+        raise VitError(rc, "vit_arena_pack_aligned")
     return arena, offsets[:n], nblocks[:n], used.value
 
 
@@ -200,9 +201,13 @@ class Hasher:
         self._check(self.lib.vit_device_status(self.handle, dev, C.byref(s)))
         return s.value
 
-    def synth_arena(self, type_, seed, first_index, n, len_each, dev=0, lens=None):
+    def synth_arena(self, type_, seed, first_index, n, len_each, dev=0, lens=None, slot_align=64):
         """Generate a framed synthetic arena on the device.  Returns a dict of
-        DeviceBuffers (arena, offsets, nblocks, digests) plus sizes."""
+        DeviceBuffers (arena, offsets, nblocks, digests) plus sizes.  slot_align
+        (a multiple of 64) rounds every slot's start up to that boundary."""
+        assert slot_align % 64 == 0 and slot_align > 0
+        if slot_align != 64 and lens is None:
+            lens = np.full(n, len_each, dtype=np.uint64)
         if lens is None:
             nb = object_blocks(type_, len_each)
             arena_bytes = nb * 64 * n
@@ -213,7 +218,8 @@ class Hasher:
             assert len(lens) == n
             nbs = np.array([object_blocks(type_, int(l)) for l in lens], dtype=np.uint64) \
                 if n < 200000 else _blocks_vec(type_, lens)
-            offsets_host = np.concatenate([[0], np.cumsum(nbs * 64)]).astype(np.uint64)
+            q = np.uint64(slot_align)
+            offsets_host = np.concatenate([[0], np.cumsum((nbs * np.uint64(64) + q - np.uint64(1)) // q * q)]).astype(np.uint64)
             arena_bytes = int(offsets_host[-1])
             offsets_host = offsets_host[:-1].copy()
             d_lens = self.alloc(8 * n, dev).upload(lens)
