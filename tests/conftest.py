@@ -33,12 +33,22 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
-def hasher():
+def _session_hasher():
     """One hasher on GPU 0 for the whole GPU session (fails loudly without a GPU)."""
     import vit_amd
     h = vit_amd.Hasher((0,))
     yield h
     h.close()
+
+
+@pytest.fixture
+def hasher(_session_hasher):
+    """The session's hasher with every option back at its default."""
+    h = _session_hasher
+    for name, value in (("kernel", 0), ("chunk_bytes", 64 << 20), ("chunk_object_multiple", 8192), ("trace", 0),
+                        ("host_threshold_bytes", 0), ("host_auto", 1)):
+        h.set_option(name, value)
+    return h
 
 
 def materialize(spec, root, oracle):

@@ -117,6 +117,37 @@ def test_slots_aligned_to_128_bytes_hash_the_same(hasher, oracle):
     assert hasher.device_status(0) == 0
 
 
+def test_pipeline_settings_do_not_change_ids(hasher, oracle, capfd):
+    """Chunk growth on or off, host lane on auto or forced low, trace printing: same ids;
+    the trace prints one line per staged chunk."""
+    rng = np.random.default_rng(99)
+    lens = rng.integers(0, 3000, size=2500).tolist() + [70_000, 300_000, 1 << 20, 65_536, 65_537]
+    blobs = [oracle.synth_bytes(49, i, L) for i, L in enumerate(lens)]
+    want = ids_of(oracle, "blob", blobs)
+    try:
+        for mult, thr, trace in ((0, None, 0), (8192, None, 1), (64, 0, 1), (8192, 65_536, 0)):
+            hasher.set_option("chunk_bytes", 1 << 20)
+            hasher.set_option("chunk_object_multiple", mult)
+            if thr is None:
+                hasher.set_option("host_auto", 1)
+            else:
+                hasher.set_option("host_threshold_bytes", thr)
+            hasher.set_option("trace", trace)
+            capfd.readouterr()
+            l0 = hasher.stat("launches")
+            assert_same(hasher.hash_blobs(blobs), want, lens)
+            err = capfd.readouterr().err
+            chunks = hasher.stat("launches") - l0
+            assert chunks >= 2
+            assert err.count("set ") == (chunks if trace else 0)
+            assert ("[vit trace] queue 0" in err) == bool(trace)
+    finally:
+        hasher.set_option("trace", 0)
+        hasher.set_option("chunk_bytes", 64 << 20)
+        hasher.set_option("chunk_object_multiple", 8192)
+        hasher.set_option("host_auto", 1)
+
+
 def test_chunked_pipeline_matches_single_chunk(hasher, oracle):
     """Force many small staging chunks so both pinned buffers cycle several times."""
     lens = [(i * 37) % 5000 for i in range(3000)]
