@@ -182,7 +182,7 @@ def main():
                    "parallelism": "file-sharded x%d, no collective" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "sha1_lds_kernel<2>" if args.kernel == "lds" else "sha1_lane_kernel",
+                     "kernel": "sha1_lds_kernel<2, 4>" if args.kernel == "lds" else "sha1_lane_kernel",
                      "kernel_ms_avg": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "the kernel is bound by integer VALU issue, not HBM: see valu",
                      "valu": {"achieved": round(valu_tops, 2), "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",

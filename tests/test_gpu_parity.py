@@ -8,7 +8,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-KERNELS = [0, 1]      # VIT_KERNEL_LDS, VIT_KERNEL_LANE
+KERNELS = [0, 1, 5]   # VIT_KERNEL_LDS (4 waves per workgroup), VIT_KERNEL_LANE, the LDS kernel with 1 wave per workgroup
 
 
 def ids_of(oracle, type_, blobs):

@@ -9,7 +9,7 @@ import numpy as np
 
 import vit_amd
 
-NAMES = {0: "lds<2>", 1: "lane", 2: "lds<1>", 3: "lds<4>"}
+NAMES = {0: "lds<2>x4", 1: "lane", 2: "lds<1>x1", 3: "lds<4>x1", 4: "lds<2>x2", 5: "lds<2>x1"}
 
 
 def main():
@@ -18,7 +18,7 @@ def main():
     L = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
     rounds = 8
     h = vit_amd.Hasher((0,))
-    b = h.synth_arena("blob", 0x5EED0002, 0, n, L)
+    b = h.synth_arena("blob", 0x5EED0002, 0, n, L, slot_align=128)
     ref = None
     times = {v: [] for v in variants}
     for v in variants:                                   # correctness + warm-up

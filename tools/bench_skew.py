@@ -32,12 +32,13 @@ def git_id(b):
 
 def mixed(a):
     h = vit_amd.Hasher((0,))
+    h.set_option("kernel", a.kernel)
     rng = np.random.default_rng(0x5EED0004)
     sizes = np.exp(rng.normal(np.log(4500.0), 1.55, a.n))
     sizes = np.minimum(sizes * (15000.0 / sizes.mean()), a.clip).astype(np.uint64)
     b = h.synth_arena("blob", 0x5EED0004, 0, a.n, 0, lens=sizes)
     nb = b["nblocks"].download(np.uint32, 4 * a.n)
-    out = {"workload": "mixed", "n": a.n, "payload_bytes": int(sizes.sum()), "arena_bytes": b["arena_bytes"],
+    out = {"workload": "mixed", "kernel": a.kernel, "n": a.n, "payload_bytes": int(sizes.sum()), "arena_bytes": b["arena_bytes"],
            "max_blocks": int(nb.max()), "clip_bytes": a.clip}
     ms0 = h.time_hash_device(b, warmup=1, iters=a.iters)
     d0 = b["digests"].download(np.uint8, 20 * a.n).reshape(-1, 20).copy()
@@ -183,6 +184,7 @@ def main():
     m.add_argument("--n", type=int, default=1_250_000)
     m.add_argument("--clip", type=int, default=32 << 20)
     m.add_argument("--iters", type=int, default=3)
+    m.add_argument("--kernel", type=int, default=0)
     s = sub.add_parser("skew")
     s.add_argument("--giants", type=int, default=4)
     s.add_argument("--giant-bytes", type=int, default=2 << 30)

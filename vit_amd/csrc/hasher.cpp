@@ -466,7 +466,7 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     if (!h || !name) return VIT_ERR_ARG;
     const std::string k(name);
     if (k == "kernel") {
-        if (value > 3) return fail(h, VIT_ERR_ARG, "unknown kernel %llu", (unsigned long long)value);
+        if (value > 5) return fail(h, VIT_ERR_ARG, "unknown kernel %llu", (unsigned long long)value);
         h->kernel = int(value);
     } else if (k == "host_threshold_bytes") { h->host_threshold = value; h->host_policy = value ? 2 : 0; }
     else if (k == "host_auto") { h->host_policy = value ? 1 : (h->host_threshold ? 2 : 0); }

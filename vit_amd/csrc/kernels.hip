@@ -116,9 +116,54 @@ __device__ __forceinline__ void hash_lane_direct(const uint8_t* first_block, uin
 }
 
 // ---------------------------------------------------------------- LDS-staged --
-// One wave per workgroup; no barrier is needed anywhere because a wave only ever
-// touches its own LDS.
-//
+// No workgroup barrier anywhere: a wave only ever touches its own slice of LDS.
+// Between its own LDS writes and reads it needs the LDS queue drained and the
+// compiler kept from moving accesses across.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The stage pipeline for a wave whose objects span more than 4 GiB: the same
+// LDS image and reads as in sha1_lds_kernel below, every load predicated, the
+// source a 64-bit address per lane and instruction (two more vector ops per
+// load than the scalar-base form).
+template <int BPS>
+__device__ __forceinline__ void far_stages(const uint8_t* arena, uint8_t* stage, const uint64_t (&src_off)[4 * BPS],
+                                        const int32_t (&lim)[4 * BPS], uint32_t my_row, uint32_t my_sw,
+                                        uint32_t my_nb, uint32_t nst, uint32_t (&h)[5])
+{
+    constexpr int LPO = 4 * BPS, ROWB = 64 * BPS;
+    auto issue = [&](uint32_t t) {
+#pragma unroll
+        for (int j = 0; j < LPO; ++j)
+            if ((int32_t)(BPS * t) < lim[j])
+                __builtin_amdgcn_global_load_lds((global_cptr)(arena + src_off[j] + (uint64_t)t * ROWB),
+                                                 (lds_ptr)(stage + j * 1024), 16, 0, 0);
+    };
+    if (nst) issue(0);
+    for (uint32_t t = 0; t < nst; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint4 q[LPO];
+#pragma unroll
+        for (int k = 0; k < LPO; ++k)
+            q[k] = *reinterpret_cast<const uint4*>(stage + my_row + ((k ^ my_sw) << 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t + 1 < nst) issue(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < BPS; ++s) {
+            if (BPS * t + s < my_nb) {
+                uint32_t w[16];
+                put_words(w, 0, q[4 * s]);     put_words(w, 4, q[4 * s + 1]);
+                put_words(w, 8, q[4 * s + 2]); put_words(w, 12, q[4 * s + 3]);
+                sha1_compress(h, w);
+            }
+        }
+    }
+}
+
 // Stage t moves blocks [BPS*t, BPS*t + BPS) of all 64 objects.  Instruction j of
 // a stage (j < LPO) serves the OPI = 64/LPO objects j*OPI .. j*OPI+OPI-1, LPO =
 // 4*BPS lanes each: lane l serves object j*OPI + l/LPO and lands at LDS byte
@@ -129,18 +174,24 @@ __device__ __forceinline__ void hash_lane_direct(const uint8_t* first_block, uin
 // lanes of every ds_read_b128 lane group hit 16 different 16-byte bank slots.
 // LDS (64*BPS*64 bytes per wave) admits 160 KiB / 8 KiB = 20 waves per CU = 5 per
 // SIMD at BPS = 2; the launch bound asks the register allocator for the same.
-template <int BPS>
-__global__ __launch_bounds__(64, BPS == 4 ? 2 : 5) void sha1_lds_kernel(DeviceBatch b)
+//
+// WPB waves share a workgroup only to get past the limit on resident
+// workgroups per CU (one-wave workgroups filled 3.6 of the 5 wave slots per
+// SIMD); each wave still works on its own 64 objects and its own slice of LDS.
+template <int BPS, int WPB>
+__global__ __launch_bounds__(64 * WPB, BPS == 4 ? 2 : (BPS == 1 ? 4 : 5)) void sha1_lds_kernel(DeviceBatch b)
 {
     constexpr int LPO  = 4 * BPS;        // lanes per object per instruction == instructions per stage
     constexpr int OPI  = 64 / LPO;       // objects per instruction
     constexpr int ROWB = 64 * BPS;       // bytes per object per stage
     constexpr int RP   = 16 / LPO > 0 ? 16 / LPO : 1;   // rows per 256-byte bank line
 
-    __shared__ __attribute__((aligned(16))) uint8_t stage[64 * ROWB];
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[WPB][64 * ROWB];
 
-    const uint32_t lane = threadIdx.x;
-    const uint32_t slot = blockIdx.x * 64u + lane;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint8_t* const stage = stage_all[wave];
+    const uint32_t slot = (blockIdx.x * WPB + wave) * 64u + lane;
 
     const Slot me = resolve_slot(b, slot);
     const uint32_t idx = me.idx, my_nb = me.nb;
@@ -153,7 +204,7 @@ __global__ __launch_bounds__(64, BPS == 4 ? 2 : 5) void sha1_lds_kernel(DeviceBa
     uint32_t* t_nb  = reinterpret_cast<uint32_t*>(stage + 64 * 8);
     t_off[lane] = my_off;
     t_nb[lane]  = my_nb;
-    __syncthreads();
+    wave_lds_sync();
 
     const uint32_t p = lane % LPO;
     const uint32_t my_sw  = (lane / RP) % LPO;
@@ -163,36 +214,40 @@ __global__ __launch_bounds__(64, BPS == 4 ? 2 : 5) void sha1_lds_kernel(DeviceBa
 
     // Wave-uniform facts: the lowest object offset of the wave is the base of
     // every fetch, a lane adds a fixed 32-bit offset to it.  That needs the 64
-    // objects within 4 GiB of each other; a wave whose objects are not (only
-    // possible in arenas beyond 4 GiB hashed in a scattering order) takes the
-    // plain per-lane loop instead.  full_stages: stages complete for all 64
-    // lanes (a lane without an object has 0 blocks, so a ragged last wave has none).
+    // objects within 4 GiB of each other.  A wave whose objects are not (an
+    // arena beyond 4 GiB hashed in binned order: equal lengths lie all over it)
+    // runs the same pipeline with a 64-bit address per lane and instruction
+    // instead (far_stages below).  full_stages: stages complete for all 64 lanes
+    // (a lane without an object has 0 blocks, so a ragged last wave has none).
     const uint32_t min_nb  = __builtin_amdgcn_readfirstlane(wave_min_u32(my_nb));
     const uint64_t min_off = wave_min_u64(my_off), max_off = wave_max_u64(my_off);
     const bool near = (max_off - min_off) < 0xFFF00000ull;
     const uint32_t full_stages = min_nb / BPS;
     const uint8_t* wave_base = b.arena + min_off;
 
-    uint32_t voff[LPO];          // this lane's source for instruction j: wave_base + voff[j] (+ stage offset)
+    uint32_t voff[LPO];          // near: this lane's source for instruction j is wave_base + voff[j] (+ stage offset)
+    uint64_t foff[LPO];          // far:  ... is arena + foff[j] (+ stage offset)
     int32_t  lim[LPO];           // instruction j is live for this lane while BPS*t < lim[j]
 #pragma unroll
     for (int j = 0; j < LPO; ++j) {
         const uint32_t o  = j * OPI + lane / LPO;          // object (lane id) served
         const uint32_t sw = (o / RP) % LPO;
         const uint32_t c  = p ^ sw;                        // chunk of the row to fetch
-        voff[j] = (uint32_t)(t_off[o] - min_off) + c * 16u;
+        const uint64_t src = t_off[o] + c * 16u;
+        if (near) voff[j] = (uint32_t)(src - min_off);
+        else      foff[j] = src;
         lim[j]  = (int32_t)t_nb[o] - (int32_t)(c >> 2);    // chunk c lies in block c/4 of the stage
     }
     // A wave that carries a long object decides when the launch ends; let it win
     // the issue arbitration against the short waves that share its SIMD.
     if (b.prio_blocks && max_nb >= b.prio_blocks) __builtin_amdgcn_s_setprio(3);
-    __syncthreads();             // table reads are done before the first DMA lands on them
+    wave_lds_sync();             // table reads are done before the first DMA lands on them
 
     uint32_t h[5];
     sha1_init(h);
 
     if (!near) {
-        hash_lane_direct(b.arena + my_off, my_nb, h);
+        far_stages<BPS>(b.arena, stage, foff, lim, my_row, my_sw, my_nb, nst, h);
         if (owns) store_digest(b.digests, idx, h);
         return;
     }
@@ -241,6 +296,11 @@ __global__ __launch_bounds__(64, BPS == 4 ? 2 : 5) void sha1_lds_kernel(DeviceBa
         // overwrite the buffer.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (FULL || t + 1 < nst) issue(t + 1, full_tag);
+        // The loads must be in flight while this stage is hashed: without the
+        // barrier the scheduler sinks them below the rounds (nothing in the
+        // arithmetic depends on them) and the wave then waits out the whole
+        // memory latency at the top of the next stage.
+        __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
         for (int s = 0; s < BPS; ++s) {
@@ -282,10 +342,15 @@ hipError_t launch_sha1(KernelVariant v, const DeviceBatch& b, hipStream_t stream
         const uint32_t grid = (b.n + 255u) / 256u;
         hipLaunchKernelGGL(sha1_lane_kernel, dim3(grid), dim3(256), 0, stream, b);
     } else {
-        const uint32_t grid = (b.n + 63u) / 64u;
-        if (int(v) == 2) hipLaunchKernelGGL(sha1_lds_kernel<1>, dim3(grid), dim3(64), 0, stream, b);
-        else if (int(v) == 3) hipLaunchKernelGGL(sha1_lds_kernel<4>, dim3(grid), dim3(64), 0, stream, b);
-        else hipLaunchKernelGGL(sha1_lds_kernel<2>, dim3(grid), dim3(64), 0, stream, b);
+        const uint32_t waves = (b.n + 63u) / 64u;
+        auto grid = [&](uint32_t wpb) { return dim3((waves + wpb - 1) / wpb); };
+        switch (int(v)) {      // 2..5: other stage depths / workgroup shapes, kept for A/B measurement
+        case 2:  hipLaunchKernelGGL((sha1_lds_kernel<1, 1>), grid(1), dim3(64), 0, stream, b); break;
+        case 3:  hipLaunchKernelGGL((sha1_lds_kernel<4, 1>), grid(1), dim3(64), 0, stream, b); break;
+        case 4:  hipLaunchKernelGGL((sha1_lds_kernel<2, 2>), grid(2), dim3(128), 0, stream, b); break;
+        case 5:  hipLaunchKernelGGL((sha1_lds_kernel<2, 1>), grid(1), dim3(64), 0, stream, b); break;
+        default: hipLaunchKernelGGL((sha1_lds_kernel<2, 4>), grid(4), dim3(256), 0, stream, b); break;
+        }
     }
     return hipGetLastError();
 }
