@@ -16,7 +16,7 @@ def main():
     variants = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [0, 1, 2, 3]
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
     L = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
-    rounds = 8
+    rounds = int(sys.argv[4]) if len(sys.argv) > 4 else 8
     h = vit_amd.Hasher((0,))
     b = h.synth_arena("blob", 0x5EED0002, 0, n, L, slot_align=128)
     ref = None
