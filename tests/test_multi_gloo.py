@@ -10,6 +10,7 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -86,3 +87,24 @@ def test_two_rank_sharding_and_reductions(tmp_path, oracle):
         want ^= np.frombuffer(oracle.blob_id(oracle.synth_bytes(99, i, int(lens[i]))), dtype=np.uint8)
     assert outs[0]["summary"] == outs[1]["summary"] == want.tolist()   # checksum of checksums over the whole job
     assert [o["first"] for o in outs] == [0, 1000]
+
+
+@pytest.mark.gpu
+def test_bench_runs_as_two_ranks_on_one_gpu():
+    """bench.py under torch.distributed.run with two ranks, as the scaling run launches it; both ranks
+    use GPU 0 here, so the timing barrier goes over gloo (RCCL refuses two ranks on one device).  The
+    line must count both ranks' blobs, and each rank hashes a different range of the synthetic stream."""
+    import json
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--blobs", "200000",
+           "--dist-backend", "gloo", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                   # rank 0 alone prints
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["device_status"] == 0
+    assert abs(d["objects_per_s"] - 2 * 200000 * 5 / (d["ms_per_step"] * 5e-3)) / d["objects_per_s"] < 0.01
+    assert abs(d["value"] - d["objects_per_s"] * 4096 / 1e9) / d["value"] < 0.01
