@@ -43,6 +43,7 @@ struct Staging {
     uint8_t*  d_arena = nullptr;  uint64_t d_cap = 0;     // device arena
     uint64_t* h_off = nullptr;    uint32_t* h_nb = nullptr;  uint32_t* h_order = nullptr;  uint8_t* h_dig = nullptr;
     uint64_t* d_off = nullptr;    uint32_t* d_nb = nullptr;  uint32_t* d_order = nullptr;  uint8_t* d_dig = nullptr;
+    uint8_t*  h_meta = nullptr;   uint8_t* d_meta = nullptr;   // the two allocations the eight pointers above point into
     uint64_t  m_cap = 0;                                  // objects the meta buffers hold
     hipEvent_t done = nullptr;
     hipEvent_t mark[4] = {nullptr, nullptr, nullptr, nullptr};   // trace only: before copy, after copy, after kernel, after read-back
@@ -138,7 +139,9 @@ uint64_t round_up(uint64_t v, uint64_t q) { return (v + q - 1) / q * q; }
 int ensure_arena(Queue& q, Staging& s, uint64_t bytes)
 {
     if (bytes <= s.h_cap && bytes <= s.d_cap) return VIT_OK;
-    const uint64_t cap = round_up(bytes < (1ull << 20) ? (1ull << 20) : bytes, 1ull << 20);
+    // Freeing and re-allocating staging costs milliseconds: start at 8 MiB and at least double.
+    const uint64_t want = std::max<uint64_t>({bytes, 8ull << 20, std::min<uint64_t>(2 * s.h_cap, 1ull << 30)});
+    const uint64_t cap = round_up(want, 1ull << 20);
     if (s.h_arena) { HIP_TRYQ(q, hipHostFree(s.h_arena)); s.h_arena = nullptr; s.h_cap = 0; }
     if (s.d_arena) { HIP_TRYQ(q, hipFree(s.d_arena)); s.d_arena = nullptr; s.d_cap = 0; }
     HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_arena), cap, hipHostMallocDefault));
@@ -148,37 +151,45 @@ int ensure_arena(Queue& q, Staging& s, uint64_t bytes)
     return VIT_OK;
 }
 
+// Offsets, block counts, order and digests of a chunk live in ONE pinned and ONE
+// device allocation (36 bytes per object): allocations cost about a millisecond
+// each, which is most of a small first call.
 int ensure_meta(Queue& q, Staging& s, uint64_t n)
 {
     if (n <= s.m_cap) return VIT_OK;
     const uint64_t cap = round_up(n < 4096 ? 4096 : n, 4096);
-    if (s.h_off) {
-        HIP_TRYQ(q, hipHostFree(s.h_off));  HIP_TRYQ(q, hipHostFree(s.h_nb));
-        HIP_TRYQ(q, hipHostFree(s.h_order)); HIP_TRYQ(q, hipHostFree(s.h_dig));
-        HIP_TRYQ(q, hipFree(s.d_off)); HIP_TRYQ(q, hipFree(s.d_nb));
-        HIP_TRYQ(q, hipFree(s.d_order)); HIP_TRYQ(q, hipFree(s.d_dig));
-        s.h_off = nullptr; s.m_cap = 0;
-    }
-    HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_off), cap * 8, hipHostMallocDefault));
-    HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_nb), cap * 4, hipHostMallocDefault));
-    HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_order), cap * 4, hipHostMallocDefault));
-    HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_dig), cap * 20, hipHostMallocDefault));
-    HIP_TRYQ(q, hipMalloc(reinterpret_cast<void**>(&s.d_off), cap * 8));
-    HIP_TRYQ(q, hipMalloc(reinterpret_cast<void**>(&s.d_nb), cap * 4));
-    HIP_TRYQ(q, hipMalloc(reinterpret_cast<void**>(&s.d_order), cap * 4));
-    HIP_TRYQ(q, hipMalloc(reinterpret_cast<void**>(&s.d_dig), cap * 20));
+    if (s.h_meta) { HIP_TRYQ(q, hipHostFree(s.h_meta)); s.h_meta = nullptr; }
+    if (s.d_meta) { HIP_TRYQ(q, hipFree(s.d_meta)); s.d_meta = nullptr; }
+    s.m_cap = 0;
+    HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_meta), cap * 36, hipHostMallocDefault));
+    HIP_TRYQ(q, hipMalloc(reinterpret_cast<void**>(&s.d_meta), cap * 36));
     s.m_cap = cap;
     return VIT_OK;
+}
+
+// Lay the four arrays out for a chunk of n objects, back to back, so that
+// offsets + block counts (+ order) travel to the device in one copy.
+// Returns the bytes of that copy without the order array; with it, 4*m more.
+uint64_t carve_meta(Staging& s, uint64_t n)
+{
+    const uint64_t m = round_up(n ? n : 1, 64);
+    auto carve = [m](uint8_t* base, uint64_t*& off, uint32_t*& nb, uint32_t*& order, uint8_t*& dig) {
+        off   = reinterpret_cast<uint64_t*>(base);
+        nb    = reinterpret_cast<uint32_t*>(base + m * 8);
+        order = reinterpret_cast<uint32_t*>(base + m * 12);
+        dig   = base + m * 16;
+    };
+    carve(s.h_meta, s.h_off, s.h_nb, s.h_order, s.h_dig);
+    carve(s.d_meta, s.d_off, s.d_nb, s.d_order, s.d_dig);
+    return m * 12;
 }
 
 void free_staging(Staging& s)
 {
     if (s.h_arena) (void)hipHostFree(s.h_arena);
     if (s.d_arena) (void)hipFree(s.d_arena);
-    if (s.h_off) {
-        (void)hipHostFree(s.h_off); (void)hipHostFree(s.h_nb); (void)hipHostFree(s.h_order); (void)hipHostFree(s.h_dig);
-        (void)hipFree(s.d_off); (void)hipFree(s.d_nb); (void)hipFree(s.d_order); (void)hipFree(s.d_dig);
-    }
+    if (s.h_meta) (void)hipHostFree(s.h_meta);
+    if (s.d_meta) (void)hipFree(s.d_meta);
     if (s.done) (void)hipEventDestroy(s.done);
     for (hipEvent_t m : s.mark) if (m) (void)hipEventDestroy(m);
     s = Staging();
@@ -247,6 +258,7 @@ int submit_chunk(Queue& q, const Job& job, Staging& s, hipStream_t stream, const
     const uint64_t bytes = blocks * 64;
     if ((rc = ensure_arena(q, s, bytes))) return rc;
     if ((rc = ensure_meta(q, s, cnt))) return rc;
+    const uint64_t meta_bytes = carve_meta(s, cnt);
 
     const auto t0 = clk::now();
     s.obj.assign(idx, idx + cnt);
@@ -269,9 +281,7 @@ int submit_chunk(Queue& q, const Job& job, Staging& s, hipStream_t stream, const
 
     if (trace) { s.host_ms[2] = double(ns_since(q.trace_t0)) * 1e-6; HIP_TRYQ(q, hipEventRecord(s.mark[0], stream)); }
     HIP_TRYQ(q, hipMemcpyAsync(s.d_arena, s.h_arena, bytes, hipMemcpyHostToDevice, stream));
-    HIP_TRYQ(q, hipMemcpyAsync(s.d_off, s.h_off, cnt * 8, hipMemcpyHostToDevice, stream));
-    HIP_TRYQ(q, hipMemcpyAsync(s.d_nb, s.h_nb, cnt * 4, hipMemcpyHostToDevice, stream));
-    if (binned) HIP_TRYQ(q, hipMemcpyAsync(s.d_order, s.h_order, cnt * 4, hipMemcpyHostToDevice, stream));
+    HIP_TRYQ(q, hipMemcpyAsync(s.d_meta, s.h_meta, meta_bytes + (binned ? meta_bytes / 3 : 0), hipMemcpyHostToDevice, stream));
     if (trace) HIP_TRYQ(q, hipEventRecord(s.mark[1], stream));
     HIP_TRYQ(q, vit::launch_sha1(vit::KernelVariant(h->kernel),
                                  make_batch(q, s.d_arena, bytes, s.d_off, s.d_nb, binned ? s.d_order : nullptr, cnt,
@@ -683,12 +693,11 @@ int vit_hash_arena(vit_hasher* h, int dev, const void* arena, uint64_t arena_byt
         s.d_cap = cap;
     }
     if (int rc = ensure_meta(*q, s, n)) return fail(h, rc, "%s", q->err.c_str());
+    const uint64_t meta_bytes = carve_meta(s, n);
     for (uint64_t i = 0; i < n; ++i) { s.h_off[i] = offsets[i] - lo; s.h_nb[i] = nblocks[i]; }
     const bool binned = vit::bin_order(s.h_nb, n, s.h_order);
     HIP_TRY(h, hipMemcpyAsync(s.d_arena, static_cast<const uint8_t*>(arena) + lo, span, hipMemcpyHostToDevice, q->stream[0]));
-    HIP_TRY(h, hipMemcpyAsync(s.d_off, s.h_off, n * 8, hipMemcpyHostToDevice, q->stream[0]));
-    HIP_TRY(h, hipMemcpyAsync(s.d_nb, s.h_nb, n * 4, hipMemcpyHostToDevice, q->stream[0]));
-    if (binned) HIP_TRY(h, hipMemcpyAsync(s.d_order, s.h_order, n * 4, hipMemcpyHostToDevice, q->stream[0]));
+    HIP_TRY(h, hipMemcpyAsync(s.d_meta, s.h_meta, meta_bytes + (binned ? meta_bytes / 3 : 0), hipMemcpyHostToDevice, q->stream[0]));
     HIP_TRY(h, vit::launch_sha1(vit::KernelVariant(h->kernel),
                                 make_batch(*q, s.d_arena, span, s.d_off, s.d_nb, binned ? s.d_order : nullptr, n, s.d_dig),
                                 q->stream[0]));
