@@ -28,7 +28,7 @@ N_BLOBS = 1_000_000
 BLOB_LEN = 4096
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (spec)
 VALU_PEAK_TOPS = 39.3216    # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: issue rate of the 3-input / shift integer ops
-OPS_PER_BLOCK = 613         # vector ops per 64-byte SHA-1 block in sha1_device.h
+OPS_PER_BLOCK = 597          # vector ops per 64-byte block: schedule 192 + rounds 400 + 5 chaining adds
 
 
 def parse():

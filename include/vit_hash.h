@@ -127,8 +127,10 @@ int vit_arena_free(vit_hasher *h, void *arena);
 
 /* Pack n objects back to back into `arena`: object i starts at offsets[i] (a
  * multiple of 64) and occupies nblocks[i]*64 bytes holding header, content,
- * 0x80, zero fill and the 64-bit big-endian bit length, i.e. exactly the bytes
- * SHA-1 compresses.  *used_bytes = total.  VIT_ERR_RANGE if arena_bytes is too
+ * 0x80, zero fill and the 64-bit big-endian bit length, i.e. exactly the words
+ * SHA-1 compresses, each 4-byte big-endian message word stored as a native
+ * little-endian dword (the 16 byte swaps per block are paid here, during the
+ * copy, and not by the kernel).  *used_bytes = total.  VIT_ERR_RANGE if arena_bytes is too
  * small (nothing written).  Host-only; needs no device.  Restates the framing
  * of reference src/commit.cpp:90-91 plus FIPS 180-4 5.1.1 padding. */
 int vit_arena_pack(const char *type, const uint8_t *const *data, const uint64_t *len,

@@ -48,8 +48,8 @@ def test_header_and_block_count(lib, oracle):
 
 
 def test_pack_layout_is_what_sha1_compresses(oracle):
-    """A packed slot = framed message + FIPS 180-4 padding: hashing its blocks with
-    a raw compression loop must give the Git id."""
+    """A packed slot = framed message + FIPS 180-4 padding, each big-endian message word
+    stored as a native little-endian dword (the kernel swaps no bytes)."""
     import vit_amd
     lens = list(range(0, 450)) + [4095, 4096, 4097, 65530]
     blobs = [oracle.synth_bytes(21, i, L) for i, L in enumerate(lens)]
@@ -63,7 +63,7 @@ def test_pack_layout_is_what_sha1_compresses(oracle):
         assert (off % 64 == 0).all()
         assert (off[1:] == off[:-1] + nb[:-1].astype(np.uint64) * 64).all()
         for i, b in enumerate(blobs):
-            slot = arena[int(off[i]):int(off[i]) + int(nb[i]) * 64].tobytes()
+            slot = arena[int(off[i]):int(off[i]) + int(nb[i]) * 64].view("<u4").byteswap().tobytes()
             framed = oracle.header(t, len(b)) + b
             assert slot[:len(framed)] == framed
             assert slot[len(framed)] == 0x80

@@ -287,11 +287,14 @@ def test_config2_full_size_1m_x_4k(hasher):
     slot = vit_amd.object_blocks("blob", L) * 64
     hl = vit_amd.header_len("blob", L)
     # generator spot check against the host restatement of the byte stream
+    # (the arena stores each big-endian message word as a native dword: byteswap gives the message bytes)
     for i in (0, 1, 999_999):
-        raw = b["arena"].download(np.uint8, slot, offset=i * slot).tobytes()
+        raw = b["arena"].download(np.uint8, slot, offset=i * slot).view("<u4").byteswap().tobytes()
         assert raw[:hl] == b"blob 4096\0" and raw[hl:hl + L] == vit_amd.synth_bytes(0x5EED0002, i, L)
 
-    mv = memoryview(b["arena"].download(np.uint8, n * slot))     # one 4.16 GB copy, main thread
+    words = b["arena"].download(np.uint8, n * slot).view("<u4")  # one 4.16 GB copy, main thread
+    words.byteswap(inplace=True)                                 # back to message byte order
+    mv = memoryview(words.view(np.uint8))
 
     def check(lo, hi):
         for i in range(lo, hi):

@@ -14,12 +14,13 @@ types = st.sampled_from(["blob", "tree", "commit"])
 
 
 def sha1_of_padded_blocks(slot):
-    """SHA-1 state update over pre-padded blocks, without any further padding:
-    what the device kernel does with an arena slot."""
+    """SHA-1 state update over pre-padded blocks whose message words are stored as
+    native little-endian dwords, without any further padding: what the device
+    kernel does with an arena slot."""
     h = [0x67452301, 0xEFCDAB89, 0x98BADCFE, 0x10325476, 0xC3D2E1F0]
     rol = lambda x, n: ((x << n) | (x >> (32 - n))) & 0xFFFFFFFF
     for off in range(0, len(slot), 64):
-        w = list(struct.unpack(">16I", slot[off:off + 64]))
+        w = list(struct.unpack("<16I", slot[off:off + 64]))
         for t in range(16, 80):
             w.append(rol(w[t - 3] ^ w[t - 8] ^ w[t - 14] ^ w[t - 16], 1))
         a, b, c, d, e = h

@@ -12,9 +12,11 @@ enum KernelVariant : int {
 };
 
 // A packed arena in device memory.  Object i occupies nblocks[i] 64-byte blocks
-// starting at arena + offsets[i]; the bytes are the framed message
+// starting at arena + offsets[i]; they hold the framed message
 // ("<type> <len>\0" + content) followed by SHA-1 padding (0x80, zeros, 64-bit
-// big-endian bit length), so the kernel hashes whole blocks and nothing else.
+// big-endian bit length), every 4-byte message word stored as a native
+// (little-endian) dword, so the kernel hashes whole blocks, swaps no bytes and
+// does nothing else.
 struct DeviceBatch {
     const uint8_t*  arena;        // device, 16-byte aligned
     uint64_t        arena_bytes;  // bytes readable from arena

@@ -371,7 +371,8 @@ __device__ __forceinline__ uint32_t ndigits_u64(uint64_t v)
 }
 
 // One wave per object; lanes stride over the object's 16-byte chunks and
-// produce header, content, 0x80, zero fill and the bit length byte by byte.
+// produce header, content, 0x80, zero fill and the bit length byte by byte,
+// each message word stored as a native dword (the arena format).
 __global__ __launch_bounds__(256) void synth_arena_kernel(SynthSpec s)
 {
     const uint32_t obj = blockIdx.x * 4u + threadIdx.x / 64u;
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256) void synth_arena_kernel(SynthSpec s)
             } else if (pos == msg) byte = 0x80;
             else if (pos >= total - 8) byte = (uint32_t)(bits >> (8 * (total - 1 - pos))) & 0xFFu;
             else byte = 0;
-            out[i >> 2] |= byte << (8 * (i & 3));
+            out[i >> 2] |= byte << (8 * (3 - (i & 3)));      // message byte 4k+j is byte 3-j of dword k
         }
         *reinterpret_cast<uint4*>(s.arena + off + c0) = make_uint4(out[0], out[1], out[2], out[3]);
     }
@@ -441,10 +442,9 @@ __global__ __launch_bounds__(256) void valu_peak_kernel(uint32_t* out, uint32_t 
     for (int i = 0; i < 16; ++i) seedw[i] = gid * 0x9E3779B9u + i * 0x85EBCA6Bu;
     for (uint32_t bl = 0; bl < blocks; ++bl) {
         uint32_t w[16];
-        // Feed the previous digest back in so nothing is loop invariant; the
-        // 16 byte swaps stand in for the ones a real block costs.
+        // Feed the previous digest back in so nothing is loop invariant.
 #pragma unroll
-        for (int i = 0; i < 16; ++i) w[i] = bswap32(seedw[i] ^ h[i % 5]);
+        for (int i = 0; i < 16; ++i) w[i] = seedw[i] ^ h[i % 5];
         sha1_compress(h, w);
     }
     if (gid < n_lanes) out[gid] = h[0] ^ h[1] ^ h[2] ^ h[3] ^ h[4];

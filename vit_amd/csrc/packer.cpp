@@ -6,13 +6,16 @@
 //   content bytes              (src/commit.cpp:91 concatenates the two)
 //   0x80, zeros                FIPS 180-4 5.1.1 padding ...
 //   8-byte big-endian bit length of header+content, ending the last block
-// so that the device kernel only ever sees whole 64-byte blocks.
+// so that the device kernel only ever sees whole 64-byte blocks; and every
+// 4-byte group of that stream is stored byte-reversed, i.e. SHA-1's big-endian
+// message word as a native little-endian dword, so that the kernel swaps
+// nothing (16 vector ops per block that the copy here absorbs for free).
 #include "../../include/vit_hash.h"
 #include "host_util.h"
 #include "packer.h"
 
 #include <cstring>
-#include <emmintrin.h>
+#include <immintrin.h>
 #include <numeric>
 
 namespace vit {
@@ -48,12 +51,22 @@ static void pack_small(const char* type, uint32_t tl, const uint8_t* data, uint6
     std::memset(slot + msg + 1, 0, size_t(total - 8 - (msg + 1)));
     const uint64_t bits = msg * 8;
     for (int i = 0; i < 8; ++i) slot[total - 8 + i] = uint8_t(bits >> (56 - 8 * i));
+    for (uint64_t o = 0; o < total; o += 4) {              // message words -> native dwords
+        uint32_t w;
+        std::memcpy(&w, slot + o, 4);
+        w = __builtin_bswap32(w);
+        std::memcpy(slot + o, &w, 4);
+    }
 }
 
-static inline void stream64(uint8_t* dst, const uint8_t* src)
+// 64 message bytes from src (any alignment) to dst (64-byte aligned): words
+// byte-reversed, non-temporal stores.
+__attribute__((target("ssse3"))) static inline void stream64(uint8_t* dst, const uint8_t* src)
 {
+    const __m128i rev = _mm_set_epi8(12, 13, 14, 15, 8, 9, 10, 11, 4, 5, 6, 7, 0, 1, 2, 3);
     for (int k = 0; k < 4; ++k)
-        _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + k, _mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + k));
+        _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + k,
+                         _mm_shuffle_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + k), rev));
 }
 
 // The staging arena is written once and next read by the copy engine, never by
@@ -62,9 +75,9 @@ static inline void stream64(uint8_t* dst, const uint8_t* src)
 // matters once packing, the copy engine and the host hash lanes share the
 // memory controllers.  The slot is 64-byte aligned; the header shifts the
 // content by hl bytes, so loads are unaligned and stores aligned.
-void pack_one(const char* type, uint32_t tl, const uint8_t* data, uint64_t len, uint8_t* slot, uint64_t nblocks)
+__attribute__((target("ssse3"))) static void pack_streaming(const char* type, uint32_t tl, const uint8_t* data,
+                                                            uint64_t len, uint8_t* slot, uint64_t nblocks)
 {
-    if (nblocks < 4 || (reinterpret_cast<uintptr_t>(slot) & 63)) { pack_small(type, tl, data, len, slot, nblocks); return; }
     alignas(64) uint8_t edge[128];
     const uint32_t hl = write_header(type, tl, len, edge);       // hl <= 31, len >= 64*3 - 40 here
     const uint64_t msg = hl + len, total = nblocks * 64;
@@ -81,6 +94,13 @@ void pack_one(const char* type, uint32_t tl, const uint8_t* data, uint64_t len, 
     for (int i = 0; i < 8; ++i) edge[left - 8 + i] = uint8_t(bits >> (56 - 8 * i));
     stream64(slot + off, edge);
     if (left == 128) stream64(slot + off + 64, edge + 64);
+}
+
+void pack_one(const char* type, uint32_t tl, const uint8_t* data, uint64_t len, uint8_t* slot, uint64_t nblocks)
+{
+    static const bool ssse3 = __builtin_cpu_supports("ssse3");
+    if (nblocks < 4 || !ssse3 || (reinterpret_cast<uintptr_t>(slot) & 63)) pack_small(type, tl, data, len, slot, nblocks);
+    else pack_streaming(type, tl, data, len, slot, nblocks);
 }
 
 void pack_fence() { _mm_sfence(); }

@@ -8,11 +8,14 @@
 //                  and the 3-way xor inside the schedule
 //   v_alignbit_b32 rotates
 //   v_add3_u32     the two 3-way adds of a round
-//   v_perm_b32     big-endian word load (byte swap)
-// which gives 613 vector ops per 64-byte block:
+// which gives 597 vector ops per 64-byte block:
 //   schedule 64 x (bitop3 + xor + alignbit)                       = 192
 //   rounds   80 x (alignbit + bitop3 + 2 x add3 + alignbit)       = 400
-//   16 byte swaps + 5 chaining adds                               =  21
+//   5 chaining adds                                               =   5
+// The 16 byte swaps a little-endian machine owes SHA-1's big-endian words are
+// paid once by whoever packs the arena (the host packer as it copies, the
+// device generator as it writes): the arena holds every message word as a
+// native dword, so a loaded register IS the word.
 //
 // Replaces the OpenSSL SHA1() call of the reference (src/commit.cpp:93-94);
 // the algorithm is FIPS 180-4 section 6.1.2.
@@ -43,7 +46,7 @@ __device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap
     VIT_ROUND(d, e, a, b, c, F, K, X((t) + 2)) VIT_ROUND(c, d, e, a, b, F, K, X((t) + 3)) \
     VIT_ROUND(b, c, d, e, a, F, K, X((t) + 4))
 
-// h: chaining value; w: the block as 16 big-endian words (destroyed).
+// h: chaining value; w: the block's 16 message words (destroyed).
 __device__ __forceinline__ void sha1_compress(uint32_t (&h)[5], uint32_t (&w)[16])
 {
     uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4];
@@ -76,10 +79,10 @@ __device__ __forceinline__ void sha1_init(uint32_t (&h)[5])
     h[3] = 0x10325476u; h[4] = 0xC3D2E1F0u;
 }
 
-// 16 raw bytes (little-endian dwords as loaded) -> 4 big-endian message words.
+// 16 arena bytes = 4 message words, already in register order.
 __device__ __forceinline__ void put_words(uint32_t (&w)[16], int at, uint4 v)
 {
-    w[at] = bswap32(v.x); w[at + 1] = bswap32(v.y); w[at + 2] = bswap32(v.z); w[at + 3] = bswap32(v.w);
+    w[at] = v.x; w[at + 1] = v.y; w[at + 2] = v.z; w[at + 3] = v.w;
 }
 
 // Digest bytes are the chaining words in big-endian order; 20 B per object,
