@@ -69,13 +69,27 @@ def c1_spec(seed):
     return [("d%02d/f%04d.bin" % (i // 100, i), seed, i, 4096) for i in range(1000)]
 
 
+def skew_spec(seed, n, oracle):
+    """The skewed worktree of tests/golden/gen_golden.py (same function): n files in t%02d/s%02d/, sizes from the
+    shared counter-based stream: 5 % empty, 75 % under 4 KiB, 17 % under 32 KiB, 2.9 % under 256 KiB, 0.1 % under 2 MiB."""
+    spec = []
+    for i in range(n):
+        r = int.from_bytes(oracle.synth_bytes(seed ^ 0x51E5, i, 8), "little")
+        cls, v = r % 1000, r >> 16
+        size = 0 if cls < 50 else v % 4096 if cls < 800 else v % 32768 if cls < 970 else v % 262144 if cls < 999 \
+            else v % (2 << 20)
+        spec.append(("t%02d/s%02d/f%05d.dat" % (i % 20, (i // 20) % 10, i), seed, i, size))
+    return spec
+
+
 @pytest.fixture(scope="session")
 def worktrees(tmp_path_factory, golden_trees, oracle):
     """Every golden worktree materialised once: name -> directory."""
     out = {}
     for name, rec in golden_trees.items():
         d = tmp_path_factory.mktemp("wt_" + name)
-        spec = c1_spec(rec["seed"]) if rec["spec"] == "c1" else rec["spec"]
+        spec = c1_spec(rec["seed"]) if rec["spec"] == "c1" else \
+            skew_spec(rec["seed"], rec["n"], oracle) if rec["spec"] == "skew" else rec["spec"]
         materialize(spec, str(d), oracle)
         out[name] = str(d)
     return out

@@ -111,6 +111,21 @@ def c1_spec():
     return [("d%02d/f%04d.bin" % (i // 100, i), SEED_C1, i, 4096) for i in range(1000)]
 
 
+def skew_spec(seed, n):
+    """n files in t%02d/s%02d/ (3 levels, 20 x 10 directories), sizes skewed like a source tree: 5 % empty,
+    75 % under 4 KiB, 17 % under 32 KiB, 2.9 % under 256 KiB, 0.1 % under 2 MiB.  Sizes come from the same
+    counter-based stream as the contents (8 bytes of stream seed^0x51E5, index i), so the fixture depends on
+    nothing but that generator.  tests/conftest.py holds the same function."""
+    spec = []
+    for i in range(n):
+        r = int.from_bytes(O.synth_bytes(seed ^ 0x51E5, i, 8), "little")
+        cls, v = r % 1000, r >> 16
+        size = 0 if cls < 50 else v % 4096 if cls < 800 else v % 32768 if cls < 970 else v % 262144 if cls < 999 \
+            else v % (2 << 20)
+        spec.append(("t%02d/s%02d/f%05d.dat" % (i % 20, (i // 20) % 10, i), seed, i, size))
+    return spec
+
+
 def quirk_specs():
     s = 0x5EED0A11
     return {
@@ -190,6 +205,8 @@ def main():
     trees = {"c1_1000x4096": dict(spec="c1", seed=SEED_C1, **tree_record(c1_spec(), with_blob_ids=True))}
     for name, spec in quirk_specs().items():
         trees[name] = dict(spec=[list(x) for x in spec], **tree_record(spec, with_blob_ids=True))
+    trees["skew_10000"] = dict(spec="skew", seed=0x5EED0003, n=10000,
+                               **tree_record(skew_spec(0x5EED0003, 10000), with_blob_ids=True))
     json.dump(trees, open(os.path.join(HERE, "trees.json"), "w"), indent=0)
     print("wrote objects.json (%d blob ids) and trees.json (%d worktrees)" % (len(out["blobs"]["ids"]), len(trees)))
     for k, v in trees.items():
