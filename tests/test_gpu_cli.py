@@ -190,3 +190,45 @@ def test_medium_worktree_skewed_sizes(oracle, tmp_path):
     want, n_blobs, n_trees = oracle.write_tree(str(wt))
     assert p.stdout.decode().strip() == want.hex()
     assert ("blobs %d trees %d" % (n_blobs, n_trees)).encode() in p.stderr
+
+
+def test_git_order_gives_gits_own_tree_ids(golden_trees, worktrees, tmp_path):
+    """`write-tree --git-order` applies Git's rules where the reference's differ (directories sort as
+    "name/", empty directories dropped, exec bit kept): on every golden worktree the id is the one
+    `git add -A && git write-tree` printed when the fixtures were generated, and without the flag the
+    reference's id stays."""
+    for name, rec in golden_trees.items():
+        wt = fresh_copy(worktrees[name], tmp_path / name)
+        assert vit(wt, "write-tree", "--git-order").stdout.decode() == rec["git_write_tree"] + "\n", name
+        assert vit(wt, "write-tree").stdout.decode() == rec["root"] + "\n", name
+
+
+def test_git_order_with_symlinks_and_special_files_matches_live_git(oracle, tmp_path):
+    """Symlinks become 120000 entries holding the target text, a fifo is passed over, a directory
+    holding only empty directories vanishes: compared with git itself on the same worktree."""
+    if not shutil.which("git"):
+        pytest.skip("no git here")
+    wt = tmp_path / "wt"
+    (wt / "src" / "deep" / "hollow" / "hollower").mkdir(parents=True)
+    (wt / "src" / "main.c").write_bytes(oracle.synth_bytes(61, 1, 5000))
+    (wt / "src.old").write_bytes(oracle.synth_bytes(61, 2, 10))
+    (wt / "src-x").write_bytes(b"")
+    (wt / "tool.sh").write_bytes(b"#!/bin/sh\n")
+    os.chmod(wt / "tool.sh", 0o755)
+    os.symlink("src/main.c", wt / "link-to-file")
+    os.symlink("src", wt / "link-to-dir")
+    os.symlink("nowhere", wt / "src" / "dangling")
+    os.mkfifo(wt / "pipe")
+    vit(str(wt), "init")
+    mine = vit(str(wt), "write-tree", "--git-order").stdout.decode().strip()
+    objs = stored_objects(str(wt))
+    shutil.rmtree(wt / ".git")
+    env = dict(os.environ, GIT_CONFIG_NOSYSTEM="1", HOME=str(tmp_path))
+    subprocess.check_call(["git", "init", "-q", "."], cwd=wt, env=env)
+    subprocess.check_call(["git", "add", "-A"], cwd=wt, env=env)
+    theirs = subprocess.check_output(["git", "write-tree"], cwd=wt, env=env).decode().strip()
+    assert mine == theirs
+    listing = subprocess.check_output(["git", "ls-tree", "-r", "-t", theirs], cwd=wt, env=env).decode()
+    for line in listing.splitlines():                     # every object git names is one we stored
+        assert line.split()[2] in objs, line
+    assert "120000" in listing and "100755" in listing and "hollow" not in listing

@@ -186,12 +186,51 @@ std::vector<int> devicesFromEnv()
     return ids;
 }
 
-struct Ent { std::string name; bool is_dir; size_t ref; };
-struct DirNode { std::string path; int depth; std::vector<Ent> ents; uint8_t id[20]; };
-struct FileRec { std::string path; uint64_t size; uint8_t id[20]; };
+enum Kind : uint8_t { REGULAR, EXECUTABLE, SYMLINK, DIRECTORY };   // the last three only under Git's rules
+struct Ent { std::string name; Kind kind; size_t ref; bool isDir() const { return kind == DIRECTORY; } };
+struct DirNode { std::string path; int depth; std::vector<Ent> ents; uint8_t id[20]; bool empty = false; };
+struct FileRec { std::string path; uint64_t size; Kind kind; uint8_t id[20]; };
 
 // What one directory listing found, before indices are assigned.
-struct Listed { std::string name; std::string path; bool is_dir; uint64_t size; };
+struct Listed { std::string name; std::string path; Kind kind; uint64_t size; };
+
+const char* modeOf(Kind k)
+{
+    switch (k) {
+    case EXECUTABLE: return "100755";
+    case SYMLINK:    return "120000";
+    case DIRECTORY:  return "40000";
+    default:         return "100644";
+    }
+}
+
+// Git's view of one directory: nothing is followed; a symlink is an entry of
+// its own, the executable bit is kept, sockets, fifos and devices are passed over.
+bool listDirGit(const std::string& dir, std::vector<Listed>& out)
+{
+    std::error_code ec;
+    fs::directory_iterator it(dir, ec), end;
+    if (ec) { std::cerr << "cannot read directory " << dir << ": " << ec.message() << '\n'; return false; }
+    for (; it != end; it.increment(ec)) {
+        if (ec) return false;
+        std::string name = it->path().filename().string();
+        if (name == ".git") continue;
+        std::error_code sec;
+        const fs::file_status st = it->symlink_status(sec);
+        if (sec) return false;
+        if (fs::is_symlink(st)) {
+            out.push_back(Listed{std::move(name), it->path().string(), SYMLINK, 0});
+        } else if (fs::is_regular_file(st)) {
+            uint64_t sz = it->file_size(sec);
+            if (sec) sz = 0;
+            const bool x = (st.permissions() & fs::perms::owner_exec) != fs::perms::none;
+            out.push_back(Listed{std::move(name), it->path().string(), x ? EXECUTABLE : REGULAR, sz});
+        } else if (fs::is_directory(st)) {
+            out.push_back(Listed{std::move(name), it->path().string(), DIRECTORY, 0});
+        }
+    }
+    return true;
+}
 
 // List one directory with the reference's rules (src/commit.cpp:143-161): skip
 // entries named ".git"; status checks follow symlinks; anything that is neither
@@ -209,9 +248,9 @@ bool listDir(const std::string& dir, std::vector<Listed>& out)
         if (it->is_regular_file(sec)) {
             uint64_t sz = it->file_size(sec);
             if (sec) sz = 0;
-            out.push_back(Listed{std::move(name), it->path().string(), false, sz});
+            out.push_back(Listed{std::move(name), it->path().string(), REGULAR, sz});
         } else if (it->is_directory(sec)) {
-            out.push_back(Listed{std::move(name), it->path().string(), true, 0});
+            out.push_back(Listed{std::move(name), it->path().string(), DIRECTORY, 0});
         } else {
             return false;
         }
@@ -223,27 +262,29 @@ bool listDir(const std::string& dir, std::vector<Listed>& out)
 // the pool, then their entries get file / directory indices serially.  dirs[0]
 // is the root.  (The reference recurses depth-first, one entry at a time; the
 // order of discovery does not enter any id, entries are sorted by name later.)
-bool walk(const std::string& root, Pool& pool, std::vector<DirNode>& dirs, std::vector<FileRec>& files)
+bool walk(const std::string& root, Pool& pool, bool git_rules, std::vector<DirNode>& dirs, std::vector<FileRec>& files)
 {
     dirs.push_back(DirNode{root, 0, {}, {}});
     std::vector<size_t> level(1, 0);
     for (int depth = 0; !level.empty(); ++depth) {
         std::vector<std::vector<Listed>> found(level.size());
         std::atomic<bool> ok{true};
-        pool.forEach(level.size(), [&](size_t k) { if (!listDir(dirs[level[k]].path, found[k])) ok = false; });
+        pool.forEach(level.size(), [&](size_t k) {
+            if (!(git_rules ? listDirGit : listDir)(dirs[level[k]].path, found[k])) ok = false;
+        });
         if (!ok) return false;
         std::vector<size_t> next;
         for (size_t k = 0; k < level.size(); ++k) {
             std::vector<Ent> ents;
             ents.reserve(found[k].size());
             for (Listed& e : found[k]) {
-                if (e.is_dir) {
-                    ents.push_back(Ent{std::move(e.name), true, dirs.size()});
+                if (e.kind == DIRECTORY) {
+                    ents.push_back(Ent{std::move(e.name), DIRECTORY, dirs.size()});
                     next.push_back(dirs.size());
                     dirs.push_back(DirNode{std::move(e.path), depth + 1, {}, {}});
                 } else {
-                    ents.push_back(Ent{std::move(e.name), false, files.size()});
-                    files.push_back(FileRec{std::move(e.path), e.size, {}});
+                    ents.push_back(Ent{std::move(e.name), e.kind, files.size()});
+                    files.push_back(FileRec{std::move(e.path), e.size, e.kind, {}});
                 }
             }
             dirs[level[k]].ents = std::move(ents);
@@ -366,7 +407,7 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
     Pool reader(io_threads_);
     const size_t root = 0;
     auto t0 = clk::now();
-    if (!walk(directoryPath, reader, dirs, files)) return {};
+    if (!walk(directoryPath, reader, git_rules_, dirs, files)) return {};
     stats_.walk_s = since(t0);
 
     // ---- blobs: bounded batches: read (pool) -> ids on the GPU -> deflate + store
@@ -379,7 +420,15 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
         while (end < files.size() && (end == pos || bytes + files[end].size <= batch_bytes_)) bytes += files[end++].size;
         contents.assign(end - pos, std::string());
         t0 = clk::now();
-        reader.forEach(end - pos, [&](size_t i) { contents[i] = slurp(files[pos + i].path, files[pos + i].size); });
+        reader.forEach(end - pos, [&](size_t i) {
+            const FileRec& f = files[pos + i];
+            if (f.kind == SYMLINK) {                       // Git stores the link's target text as the blob
+                std::error_code ec;
+                contents[i] = fs::read_symlink(f.path, ec).string();
+            } else {
+                contents[i] = slurp(f.path, f.size);
+            }
+        });
         stats_.read_s += since(t0);
         std::vector<std::string> ids = writeObjects("blob", contents);
         if (ids.size() != contents.size()) return {};
@@ -401,19 +450,43 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
         std::vector<std::string> contents(level.size());
         for (size_t k = 0; k < level.size(); ++k) {
             DirNode& d = dirs[level[k]];
-            // reference src/commit.cpp:164-165: plain std::string order of the names
-            std::sort(d.ents.begin(), d.ents.end(), [](const Ent& a, const Ent& b) { return a.name < b.name; });
+            if (git_rules_) {
+                // Git compares a directory as "name/" and has no entry for a directory without files below it
+                d.ents.erase(std::remove_if(d.ents.begin(), d.ents.end(),
+                                            [&](const Ent& e) { return e.isDir() && dirs[e.ref].empty; }), d.ents.end());
+                std::sort(d.ents.begin(), d.ents.end(), [](const Ent& a, const Ent& b) {
+                    return (a.isDir() ? a.name + '/' : a.name) < (b.isDir() ? b.name + '/' : b.name);
+                });
+                d.empty = d.ents.empty();
+            } else {
+                // reference src/commit.cpp:164-165: plain std::string order of the names
+                std::sort(d.ents.begin(), d.ents.end(), [](const Ent& a, const Ent& b) { return a.name < b.name; });
+            }
             std::string& c = contents[k];
             for (const Ent& e : d.ents) {                  // :167-171
-                c += e.is_dir ? "40000" : "100644";
+                c += git_rules_ ? modeOf(e.kind) : (e.isDir() ? "40000" : "100644");
                 c += ' ';
                 c += e.name;
                 c += '\0';
-                c.append(reinterpret_cast<const char*>(e.is_dir ? dirs[e.ref].id : files[e.ref].id), 20);
+                c.append(reinterpret_cast<const char*>(e.isDir() ? dirs[e.ref].id : files[e.ref].id), 20);
             }
         }
-        std::vector<std::string> ids = writeObjects("tree", contents);
-        if (ids.size() != contents.size()) return {};
+        // Under Git's rules an empty directory has no tree object at all (the root excepted: an empty
+        // worktree is the empty tree); hashing it anyway is harmless, storing it is not wanted.
+        std::vector<std::string> ids;
+        if (git_rules_ && depth > 0) {
+            std::vector<std::string> kept;
+            std::vector<size_t> at;
+            for (size_t k = 0; k < level.size(); ++k)
+                if (!dirs[level[k]].empty) { at.push_back(k); kept.push_back(std::move(contents[k])); }
+            std::vector<std::string> some = writeObjects("tree", kept);
+            if (some.size() != kept.size()) return {};
+            ids.assign(level.size(), std::string(40, '0'));
+            for (size_t j = 0; j < at.size(); ++j) ids[at[j]] = some[j];
+        } else {
+            ids = writeObjects("tree", contents);
+            if (ids.size() != contents.size()) return {};
+        }
         for (size_t k = 0; k < level.size(); ++k)
             for (int b = 0; b < 20; ++b)
                 dirs[level[k]].id[b] = uint8_t(hexNibble(ids[k][2 * b]) * 16 + hexNibble(ids[k][2 * b + 1]));

@@ -71,6 +71,12 @@ public:
     // is the hash of its content, so the bytes would be the same.  false: always rewrite, as the
     // reference does (src/commit.cpp:108-111).
     void setSkipExisting(bool on) { skip_existing_ = on; }
+    // false (default): writeTree builds the tree the REFERENCE builds (src/commit.cpp:139-173), which differs
+    // from Git's where a directory name is a prefix of a sibling's, for empty directories, executables and
+    // symlinks.  true: Git's own rules instead: directories sort as "name/", empty directories are left out,
+    // executables get mode 100755, symlinks are stored as 120000 blobs holding the link target, other special
+    // files are ignored; the id is then what `git add -A && git write-tree` gives on a worktree without ignore rules.
+    void setGitTreeRules(bool on) { git_rules_ = on; }
     void setIoThreads(int n) { io_threads_ = n < 1 ? 1 : n; }
     void setBatchBytes(uint64_t b) { batch_bytes_ = b; }
     const StoreStats& lastStats() const { return stats_; }
@@ -82,6 +88,7 @@ private:
     vit_hasher* hasher_ = nullptr;
     bool store_ = true;
     bool skip_existing_ = true;
+    bool git_rules_ = false;
     int io_threads_ = 8;
     uint64_t batch_bytes_ = 1ull << 30;
     StoreStats stats_;

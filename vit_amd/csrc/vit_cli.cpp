@@ -3,7 +3,8 @@
 //
 //   vit init
 //   vit hash-object -w <file>            reference src/main.cpp:90-120
-//   vit write-tree [--stats] [--no-store] [--rewrite]    reference src/main.cpp:155-163
+//   vit write-tree [--stats] [--no-store] [--rewrite] [--git-order]    reference src/main.cpp:155-163
+//                                        (--git-order: Git's tree rules where the reference's differ)
 //   vit commit-tree <tree> -p <parent> -m <message>   reference src/main.cpp:165-186
 //   vit cat-file -p <hash>               reference src/main.cpp:68-88
 //   vit ls-tree <hash> --name-only|-l    reference src/main.cpp:122-153
@@ -74,6 +75,7 @@ bool cmdWriteTree(int argc, char** argv)
         if (!std::strcmp(argv[i], "--stats")) stats = true;
         else if (!std::strcmp(argv[i], "--no-store")) vit::defaultStore().setStoreObjects(false);
         else if (!std::strcmp(argv[i], "--rewrite")) vit::defaultStore().setSkipExisting(false);
+        else if (!std::strcmp(argv[i], "--git-order")) vit::defaultStore().setGitTreeRules(true);
         else { std::cerr << "Unknown flag: " << argv[i] << '\n'; return false; }
     }
     const std::string id = writeTree(".");
