@@ -58,7 +58,8 @@ def build_cli(force=False, verbose=False):
     if not force and not _stale(CLI, srcs) and os.path.getmtime(CLI) >= os.path.getmtime(LIB):
         return CLI
     os.makedirs(os.path.dirname(CLI), exist_ok=True)
-    cmd = [_hipcc()] + COMMON + ["-o", CLI] + srcs + [
+    # host-only sources: no device pass (hipcc would otherwise compile them for its default GPU too)
+    cmd = [_hipcc()] + COMMON + ["-x", "c++", "-o", CLI] + srcs + [
         "-L" + HERE, "-lvit_hash", "-Wl,-rpath,$ORIGIN/..", "-lz", "-lpthread"]
     if verbose:
         print(" ".join(cmd))

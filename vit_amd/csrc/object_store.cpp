@@ -107,29 +107,63 @@ int hexNibble(char c)
     return -1;
 }
 
-std::string frame(const std::string& type, const std::string& content)
-{
-    std::string full;
-    full.reserve(type.size() + 24 + content.size());
-    full += type;
-    full += ' ';
-    full += std::to_string(content.size());
-    full += '\0';
-    full += content;
-    return full;
-}
+// The zlib stream compress() produces at the default level (reference
+// src/commit.cpp:98-105), without what compress() costs per call: it sets up and
+// tears down a deflate state (about 270 KB of allocations) for every object and
+// wants header and content copied into one buffer first.  One state per thread
+// is reset between objects, and header and content are fed as two pieces;
+// deflate's output does not depend on how its input is cut, so the bytes are
+// the ones compress() gives (tests compare them).
+class Deflater {
+public:
+    Deflater()
+    {
+        std::memset(&zs_, 0, sizeof zs_);
+        ok_ = deflateInit(&zs_, Z_DEFAULT_COMPRESSION) == Z_OK;
+    }
+    ~Deflater() { if (ok_) deflateEnd(&zs_); }
+    Deflater(const Deflater&) = delete;
+    Deflater& operator=(const Deflater&) = delete;
 
-// zlib compress() at the default level, as reference src/commit.cpp:98-105.
+    bool run(const std::string& type, const std::string& content, std::string& out)
+    {
+        if (!ok_ || deflateReset(&zs_) != Z_OK) return false;
+        std::string header = type;
+        header += ' ';
+        header += std::to_string(content.size());
+        header += '\0';
+        out.resize(deflateBound(&zs_, uLong(header.size() + content.size())));
+        zs_.next_out = reinterpret_cast<Bytef*>(&out[0]);
+        zs_.avail_out = uInt(out.size());
+        zs_.next_in = reinterpret_cast<Bytef*>(&header[0]);
+        zs_.avail_in = uInt(header.size());
+        if (deflate(&zs_, Z_NO_FLUSH) != Z_OK) return false;
+        // avail_in is 32 bits wide: a content of 4 GiB or more goes in slices
+        const Bytef* p = reinterpret_cast<const Bytef*>(content.data());
+        size_t left = content.size();
+        for (;;) {
+            const size_t take = std::min<size_t>(left, 1u << 30);
+            zs_.next_in = const_cast<Bytef*>(p);
+            zs_.avail_in = uInt(take);
+            p += take;
+            left -= take;
+            const int rc = deflate(&zs_, left ? Z_NO_FLUSH : Z_FINISH);
+            if (!left) { if (rc != Z_STREAM_END) return false; break; }
+            if (rc != Z_OK) return false;
+        }
+        out.resize(out.size() - zs_.avail_out);
+        return true;
+    }
+
+private:
+    z_stream zs_;
+    bool ok_ = false;
+};
+
 bool deflateFramed(const std::string& type, const std::string& content, std::string& out)
 {
-    const std::string full = frame(type, content);
-    uLongf dst = compressBound(uLong(full.size()));
-    out.resize(dst);
-    if (compress(reinterpret_cast<Bytef*>(&out[0]), &dst, reinterpret_cast<const Bytef*>(full.data()),
-                 uLong(full.size())) != Z_OK)
-        return false;
-    out.resize(dst);
-    return true;
+    static thread_local Deflater deflater;
+    return deflater.run(type, content, out);
 }
 
 // Write atomically: a reader (or a crash) never sees a half-written object.
