@@ -26,8 +26,8 @@ struct DeviceBatch {
     uint32_t        n;
     uint8_t*        digests;      // device, n * 20 bytes, indexed by object
     uint32_t*       status;       // device word, OR-ed with STATUS_* bits on bad input
-    uint32_t        prio_blocks;  // waves whose longest object has >= this many blocks run at raised
-                                  // priority (0 = off): a long object is the batch's critical path
+    uint64_t*       wave_trace;   // diagnostics, normally nullptr: 4 words per wave (start and end of the wave on the
+                                  // 100 MHz wall clock, hardware id, longest object in blocks)
 };
 
 enum : uint32_t {

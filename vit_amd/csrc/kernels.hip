@@ -115,6 +115,17 @@ __device__ __forceinline__ void hash_lane_direct(const uint8_t* first_block, uin
     }
 }
 
+// Diagnostics: when and where a wave ran (DeviceBatch::wave_trace).  HW_ID (hardware register 4)
+// holds wave, SIMD, CU, SH and SE ids, XCC_ID (register 20) the XCD.
+__device__ __forceinline__ void trace_wave(uint64_t* trace, uint32_t wave_index, uint64_t t0, uint64_t tag)
+{
+    uint64_t* rec = trace + (uint64_t)wave_index * 4u;
+    rec[0] = t0;
+    rec[1] = wall_clock64();
+    rec[2] = (uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((uint64_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+    rec[3] = tag;
+}
+
 // ---------------------------------------------------------------- LDS-staged --
 // No workgroup barrier anywhere: a wave only ever touches its own slice of LDS.
 // Between its own LDS writes and reads it needs the LDS queue drained and the
@@ -193,6 +204,7 @@ __global__ __launch_bounds__(64 * WPB, BPS == 4 ? 2 : (BPS == 1 ? 4 : 5)) void s
     uint8_t* const stage = stage_all[wave];
     const uint32_t slot = (blockIdx.x * WPB + wave) * 64u + lane;
 
+    const uint64_t trace_t0 = b.wave_trace ? wall_clock64() : 0;
     const Slot me = resolve_slot(b, slot);
     const uint32_t idx = me.idx, my_nb = me.nb;
     const uint64_t my_off = me.off;
@@ -238,9 +250,6 @@ __global__ __launch_bounds__(64 * WPB, BPS == 4 ? 2 : (BPS == 1 ? 4 : 5)) void s
         else      foff[j] = src;
         lim[j]  = (int32_t)t_nb[o] - (int32_t)(c >> 2);    // chunk c lies in block c/4 of the stage
     }
-    // A wave that carries a long object decides when the launch ends; let it win
-    // the issue arbitration against the short waves that share its SIMD.
-    if (b.prio_blocks && max_nb >= b.prio_blocks) __builtin_amdgcn_s_setprio(3);
     wave_lds_sync();             // table reads are done before the first DMA lands on them
 
     uint32_t h[5];
@@ -249,6 +258,7 @@ __global__ __launch_bounds__(64 * WPB, BPS == 4 ? 2 : (BPS == 1 ? 4 : 5)) void s
     if (!near) {
         far_stages<BPS>(b.arena, stage, foff, lim, my_row, my_sw, my_nb, nst, h);
         if (owns) store_digest(b.digests, idx, h);
+        if (b.wave_trace && lane == 0) trace_wave(b.wave_trace, slot / 64u, trace_t0, max_nb | (1ull << 40));
         return;
     }
 
@@ -318,6 +328,7 @@ __global__ __launch_bounds__(64 * WPB, BPS == 4 ? 2 : (BPS == 1 ? 4 : 5)) void s
     for (; t + 1 < full_stages; ++t) stage_body(t, std::true_type());
     for (; t < nst; ++t) stage_body(t, std::false_type());
     if (owns) store_digest(b.digests, idx, h);
+    if (b.wave_trace && lane == 0) trace_wave(b.wave_trace, slot / 64u, trace_t0, max_nb);
 }
 
 // ------------------------------------------------------------- lane-direct --
