@@ -148,6 +148,33 @@ def test_pipeline_settings_do_not_change_ids(hasher, oracle, capfd):
         hasher.set_option("host_auto", 1)
 
 
+def test_wave_timeline_diagnostic_records_every_wave(hasher, oracle):
+    """With a trace buffer set, every wave of the launch writes when and where it ran; ids unchanged."""
+    n, L = 3000, 700
+    b = hasher.synth_arena("blob", 91, 0, n, L)
+    want = hasher.hash_device(b).copy()
+    waves = (n + 255) // 256 * 4
+    tr = hasher.alloc(32 * waves)
+    tr.upload(np.zeros(4 * waves, dtype=np.uint64))
+    try:
+        hasher.set_option("wave_trace_ptr", tr.ptr)
+        got = hasher.hash_device(b)
+    finally:
+        hasher.set_option("wave_trace_ptr", 0)
+    assert (got == want).all()
+    assert got[5].tobytes() == oracle.object_id("blob", oracle.synth_bytes(91, 5, L))
+    rec = tr.download(np.uint64, 32 * waves).reshape(-1, 4)
+    live = (n + 63) // 64
+    assert (rec[:live, 1] > rec[:live, 0]).all() and (rec[:live, 0] > 0).all()
+    assert (rec[:live, 3] == hasher_blocks(L)).all()
+    assert (rec[live:, 3] == 0).all()                      # a wave without objects records 0 blocks
+
+
+def hasher_blocks(L):
+    import vit_amd
+    return vit_amd.object_blocks("blob", L)
+
+
 def test_chunked_pipeline_matches_single_chunk(hasher, oracle):
     """Force many small staging chunks so both pinned buffers cycle several times."""
     lens = [(i * 37) % 5000 for i in range(3000)]
