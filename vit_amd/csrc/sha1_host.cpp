@@ -109,6 +109,7 @@ HostSha1::HostSha1() : nbytes_(0)
 
 void HostSha1::update(const void* data, size_t len)
 {
+    if (len == 0) return;                               // (an empty object passes a null pointer)
     const uint8_t* p = static_cast<const uint8_t*>(data);
     size_t have = size_t(nbytes_ & 63);
     nbytes_ += len;
