@@ -297,6 +297,35 @@ def test_waves_spanning_more_than_4gib_take_the_per_lane_path(hasher):
         assert far[i].tobytes() == want
 
 
+def test_binned_skewed_arena_beyond_4gib_keeps_its_rate(hasher):
+    """A coarse guard on speed, not a benchmark: a skewed batch in an arena beyond 4 GiB, hashed in binned
+    order (every wave's objects lie all over the arena), must stay within 2.2x of the time the same number
+    of blocks takes on uniform objects.  (Sending such waves to a plain per-lane loop once cost 2.6x.)"""
+    import vit_amd
+    n = 340_000
+    rng = np.random.default_rng(5)
+    sizes = np.exp(rng.normal(np.log(4500.0), 1.55, n))
+    sizes = np.minimum(sizes * (15000.0 / sizes.mean()), 131072).astype(np.uint64)
+    b = hasher.synth_arena("blob", 0x5EED0044, 0, n, 0, lens=sizes)
+    assert b["arena_bytes"] > (1 << 32)
+    nb = b["nblocks"].download(np.uint32, 4 * n)
+    order_host, differs = vit_amd.bin_order(nb)
+    assert differs
+    order = hasher.alloc(4 * n).upload(order_host)
+    skew_ms = min(hasher.time_hash_device(b, order=order, warmup=1, iters=3))
+    got = b["digests"].download(np.uint8, 20 * n).reshape(-1, 20)
+    for i in (0, 7, n - 1, int(np.argmax(sizes))):
+        want = hashlib.sha1(b"blob %d\0" % int(sizes[i]) + vit_amd.synth_bytes(0x5EED0044, i, int(sizes[i]))).digest()
+        assert got[i].tobytes() == want
+    del b
+    u = hasher.synth_arena("blob", 1, 0, 200_000, 4096)
+    uni_ms = min(hasher.time_hash_device(u, warmup=1, iters=3))
+    per_block = uni_ms / (200_000 * 65)
+    floor_ms = float(nb.astype(np.uint64).sum()) * per_block
+    print("skewed %.3f ms, floor %.3f ms, ratio %.2f" % (skew_ms, floor_ms, skew_ms / floor_ms))
+    assert skew_ms < 2.2 * floor_ms, (skew_ms, floor_ms)
+
+
 def test_config2_full_size_1m_x_4k(hasher):
     """BASELINE configs[1] at full size: 1,000,000 x 4 KiB blobs generated on the
     device; every digest checked against hashlib (OpenSSL) on the host copy of the
