@@ -156,6 +156,13 @@ int vit_arena_pack_aligned(const char *type, const uint8_t *const *data, const u
  * (order is then the identity and may be omitted), negative on error. */
 int vit_bin_order(const uint32_t *nblocks, uint64_t n, uint32_t *order);
 
+/* The same permutation computed on the device, for arenas whose block counts
+ * never were in host memory: d_nblocks and d_order are device pointers on
+ * queue `dev`; asynchronous on `stream` (NULL = the queue's own).  The library
+ * keeps the sort's scratch memory (about 8 bytes per object) with the queue. */
+int vit_bin_order_device(vit_hasher *h, int dev, const uint32_t *d_nblocks, uint64_t n,
+                         uint32_t *d_order, void *stream);
+
 /* The multi-GPU partition vit_hash_objects applies: queue_of[i] = device queue
  * (0 .. n_queues-1) that hashes object i, balanced by block count (bytes), not
  * by object count; objects that are large against a fair share are placed

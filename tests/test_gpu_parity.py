@@ -175,6 +175,24 @@ def hasher_blocks(L):
     return vit_amd.object_blocks("blob", L)
 
 
+def test_device_binning_gives_the_host_order(hasher):
+    """vit_bin_order_device = vit_bin_order: longest first, ties in index order; and the ids under it."""
+    import vit_amd
+    rng = np.random.default_rng(77)
+    for n in (1, 63, 1000, 70_001):
+        lens = rng.integers(0, 9000, size=n).astype(np.uint64)
+        lens[rng.integers(0, n, size=max(n // 50, 1))] = 200_000
+        b = hasher.synth_arena("blob", 0x5EED0077, 0, n, 0, lens=lens)
+        nb = b["nblocks"].download(np.uint32, 4 * n)
+        want, _ = vit_amd.bin_order(nb)
+        d_order = hasher.bin_order_device(b)
+        got = d_order.download(np.uint32, 4 * n)
+        assert (got == want).all(), n
+        plain = hasher.hash_device(b).copy()
+        assert (hasher.hash_device(b, order=d_order) == plain).all()
+    assert hasher.device_status() == 0
+
+
 def test_chunked_pipeline_matches_single_chunk(hasher, oracle):
     """Force many small staging chunks so both pinned buffers cycle several times."""
     lens = [(i * 37) % 5000 for i in range(3000)]

@@ -46,6 +46,11 @@ def mixed(a):
     order_host, differs = vit_amd.bin_order(nb)
     out["bin_order_host_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
     order = h.alloc(4 * a.n).upload(order_host)
+    h.bin_order_device(b); h.sync()                        # first call sizes the sort's scratch memory
+    t0 = time.perf_counter()
+    d_order = h.bin_order_device(b); h.sync()
+    out["bin_order_device_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+    out["device_order_equals_host_order"] = bool((d_order.download(np.uint32, 4 * a.n) == order_host).all())
     b["digests"].upload(np.zeros(20 * a.n, dtype=np.uint8))
     ms1 = h.time_hash_device(b, order=order, warmup=1, iters=a.iters)
     d1 = b["digests"].download(np.uint8, 20 * a.n).reshape(-1, 20)

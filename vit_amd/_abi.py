@@ -38,6 +38,7 @@ SIGNATURES = {
     "vit_arena_pack_aligned": (C.c_int, [C.c_char_p, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, u64p, C.c_int,
                                          C.c_uint32]),
     "vit_bin_order": (C.c_int, [vp, C.c_uint64, vp]),
+    "vit_bin_order_device": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp]),
     "vit_shard_plan": (C.c_int, [vp, C.c_uint64, C.c_int, vp]),
     "vit_hash_arena": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp, C.c_uint64, vp]),
     "vit_hash_arena_device": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp]),

@@ -57,6 +57,7 @@ struct Queue {
     hipStream_t stream[3] = {nullptr, nullptr, nullptr};   // [0],[1]: alternating chunks; [2]: long objects
     uint32_t* d_status = nullptr;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    void* sort_scratch = nullptr; size_t sort_scratch_bytes = 0;   // vit_bin_order_device
     std::vector<hipEvent_t> timing;                       // pool for vit_time_hash_device
     std::string trace_log;                                // per-chunk timeline of the last call, when tracing
     clk::time_point trace_t0;
@@ -465,6 +466,7 @@ void vit_hasher_destroy(vit_hasher* h)
         if (q.d_status) (void)hipFree(q.d_status);
         if (q.ev_a) (void)hipEventDestroy(q.ev_a);
         if (q.ev_b) (void)hipEventDestroy(q.ev_b);
+        if (q.sort_scratch) (void)hipFree(q.sort_scratch);
         for (hipEvent_t e : q.timing) (void)hipEventDestroy(e);
         for (hipStream_t st : q.stream) if (st) (void)hipStreamDestroy(st);
     }
@@ -731,6 +733,26 @@ int vit_hash_arena_device(vit_hasher* h, int dev, const void* d_arena, uint64_t 
     HIP_TRY(h, vit::launch_sha1(vit::KernelVariant(h->kernel),
                                 make_batch(*q, d_arena, arena_bytes, d_offsets, d_nblocks, d_order, n, d_digests), s));
     ++h->launches; h->objects_gpu += n;
+    return VIT_OK;
+}
+
+int vit_bin_order_device(vit_hasher* h, int dev, const uint32_t* d_nblocks, uint64_t n, uint32_t* d_order, void* stream)
+{
+    Queue* q = queue_of(h, dev);
+    if (!q) return h ? fail(h, VIT_ERR_ARG, "no device queue %d", dev) : VIT_ERR_ARG;
+    if (n == 0) return VIT_OK;
+    if (!d_nblocks || !d_order) return fail(h, VIT_ERR_ARG, "null argument");
+    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 objects in one call");
+    HIP_TRY(h, hipSetDevice(q->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : q->stream[0];
+    const size_t need = vit::bin_order_scratch_bytes(uint32_t(n));
+    if (need > q->sort_scratch_bytes) {
+        HIP_TRY(h, hipStreamSynchronize(s));              // an earlier sort may still be using the old block
+        if (q->sort_scratch) { HIP_TRY(h, hipFree(q->sort_scratch)); q->sort_scratch = nullptr; q->sort_scratch_bytes = 0; }
+        HIP_TRY(h, hipMalloc(&q->sort_scratch, need));
+        q->sort_scratch_bytes = need;
+    }
+    HIP_TRY(h, vit::bin_order_device(d_nblocks, uint32_t(n), d_order, q->sort_scratch, q->sort_scratch_bytes, s));
     return VIT_OK;
 }
 

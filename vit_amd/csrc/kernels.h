@@ -58,6 +58,13 @@ struct SynthSpec {
 };
 hipError_t launch_synth(const SynthSpec& s, hipStream_t stream);
 
+// Length binning on the device: order[] = object indices by block count, longest first, ties in
+// index order (the same permutation the host routine gives), for arenas whose block counts never
+// were in host memory.  scratch: device memory of at least bin_order_scratch_bytes(n).
+size_t bin_order_scratch_bytes(uint32_t n);
+hipError_t bin_order_device(const uint32_t* d_nblocks, uint32_t n, uint32_t* d_order, void* scratch,
+                            size_t scratch_bytes, hipStream_t stream);
+
 // Compute-only ceiling: every lane runs `blocks_per_lane` SHA-1 compressions on
 // register-resident data (no loads in the loop).  out: one dword per lane.
 hipError_t launch_valu_peak(uint32_t* out, uint32_t n_lanes, uint32_t blocks_per_lane,

@@ -20,6 +20,8 @@
 #include "kernels.h"
 #include "sha1_device.h"
 
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include <type_traits>
 
 namespace vit {
@@ -440,6 +442,45 @@ hipError_t launch_synth(const SynthSpec& s, hipStream_t stream)
     if (s.n == 0) return hipSuccess;
     hipLaunchKernelGGL(synth_arena_kernel, dim3((s.n + 3u) / 4u), dim3(256), 0, stream, s);
     return hipGetLastError();
+}
+
+// ------------------------------------------------------------ device binning --
+__global__ __launch_bounds__(256) void iota_kernel(uint32_t* out, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
+// scratch = [sorted keys, n dwords][0..n-1, n dwords][rocPRIM's own temporary storage]
+static size_t sort_temp_bytes(uint32_t n)
+{
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs_desc(nullptr, bytes, static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+                                         static_cast<const uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), n, 0, 32);
+    return bytes;
+}
+
+size_t bin_order_scratch_bytes(uint32_t n)
+{
+    const size_t lists = (size_t(n) * 8 + 255) / 256 * 256;
+    return lists + sort_temp_bytes(n) + 256;
+}
+
+hipError_t bin_order_device(const uint32_t* d_nblocks, uint32_t n, uint32_t* d_order, void* scratch,
+                            size_t scratch_bytes, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    if (scratch_bytes < bin_order_scratch_bytes(n)) return hipErrorInvalidValue;
+    uint32_t* keys_out = static_cast<uint32_t*>(scratch);
+    uint32_t* iota = keys_out + n;
+    const size_t lists = (size_t(n) * 8 + 255) / 256 * 256;
+    void* temp = static_cast<uint8_t*>(scratch) + lists;
+    size_t temp_bytes = scratch_bytes - lists;
+    hipLaunchKernelGGL(iota_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, iota, n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // a stable sort by descending key keeps equal block counts in index order
+    return rocprim::radix_sort_pairs_desc(temp, temp_bytes, d_nblocks, keys_out, iota, d_order, n, 0, 32, stream);
 }
 
 // --------------------------------------------------------- compute ceiling --

@@ -236,6 +236,13 @@ class Hasher:
         return dict(arena=arena, offsets=offsets, nblocks=nblocks, digests=digests, n=n,
                     arena_bytes=arena_bytes, lens=d_lens, dev=dev)
 
+    def bin_order_device(self, batch):
+        """Length-binning order of a device-resident batch, computed on the device; returns a DeviceBuffer."""
+        order = self.alloc(4 * max(batch["n"], 1), batch["dev"])
+        self._check(self.lib.vit_bin_order_device(self.handle, batch["dev"], batch["nblocks"].ptr, batch["n"],
+                                                  order.ptr, None))
+        return order
+
     def hash_device(self, batch, order=None):
         """Launch on a batch from synth_arena(); returns digests as (n, 20)."""
         self._check(self.lib.vit_hash_arena_device(
