@@ -3,13 +3,15 @@
 // Host pipeline of vit_hash_objects(), per device queue:
 //
 //   pack chunk k+1 into pinned arena B   |  H2D copy, kernel, digest D2H of
-//   (header, memcpy, padding; threads)   |  chunk k from pinned arena A (stream)
+//   (header, content, padding; threads)  |  chunk k from pinned arena A (stream)
 //
 // Two staging sets per queue alternate, so host packing overlaps the copy
-// engine and the kernel.  Objects are assigned to queues by padded size (bytes),
-// not by count; nothing is exchanged between devices because every digest
-// depends on its own object only and the consumer of the digests (tree
-// assembly, reference src/commit.cpp:164-172) runs on the host.
+// engine and the kernel; a third set and stream carry the chunks of long
+// objects, and the longest objects of a skewed batch are hashed by host
+// threads meanwhile (see vit_hash_objects).  Objects are assigned to queues by
+// padded size (bytes), not by count; nothing is exchanged between devices
+// because every digest depends on its own object only and the consumer of the
+// digests (tree assembly, reference src/commit.cpp:164-172) runs on the host.
 #include "../../include/vit_hash.h"
 #include "host_util.h"
 #include "kernels.h"
