@@ -24,6 +24,19 @@ def declared_functions():
     return sorted(set(re.findall(r"\b(vit_[a-z0-9_]+)\s*\(", text)))
 
 
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: the header alone must compile as C99, warnings as errors."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc here")
+    src = tmp_path / "use.c"
+    src.write_text('#include "vit_hash.h"\nint main(void) { vit_hasher *h = 0; (void)h; return VIT_OK; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                        "-fsyntax-only", str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_library_exports_every_declared_symbol(lib):
     from vit_amd import _abi
     names = declared_functions()
