@@ -113,6 +113,13 @@ int vit_hash_objects(vit_hasher *h, const char *type, const uint8_t *const *data
 int vit_hash_blobs(vit_hasher *h, const uint8_t *const *data, const uint64_t *len,
                    uint64_t n, uint8_t *digests);
 
+/* Plain SHA-1 of n buffers, no Git framing: digest i = SHA1(data[i], len[i]).
+ * This is the reference's call itself, n at a time: src/commit.cpp:93-94 passes
+ * SHA1() the already framed "<type> <len>\0" + content string.  Same pipeline
+ * and scheduling as vit_hash_objects. */
+int vit_sha1_buffers(vit_hasher *h, const uint8_t *const *data, const uint64_t *len,
+                     uint64_t n, uint8_t *digests);
+
 /* id of ONE object computed on the calling host thread (SHA-NI when the CPU has
  * it).  This is the routine the scheduler applies to objects above
  * "host_threshold_bytes"; exported so that path can be checked on its own.

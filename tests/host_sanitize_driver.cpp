@@ -2,6 +2,7 @@
 // tests/test_sanitize_host.py): random batches, content buffers of exact size, every packed slot
 // compared byte for byte with the framed, padded, word-swapped message.
 #include "vit_hash.h"
+#include "packer.h"
 #include "sha1_host.h"
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +39,19 @@ int main() {
             }
             uint8_t d1[20];
             vit::host_object_id("blob", ptr[i], len[i], d1);
+            vit::host_object_id(nullptr, ptr[i], len[i], d1);
+            // the same buffer without Git framing (type length 0), as vit_sha1_buffers packs it
+            const uint64_t rb = (len[i] + 9 + 63) / 64;
+            void* raw = nullptr;
+            if (posix_memalign(&raw, 64, rb * 64)) return 2;
+            vit::pack_one(nullptr, 0, ptr[i], len[i], static_cast<uint8_t*>(raw), rb);
+            vit::pack_fence();
+            const uint8_t* r = static_cast<uint8_t*>(raw);
+            for (uint64_t p = 0; p < rb * 64; ++p) {
+                uint8_t want = p < len[i] ? blobs[i][p] : p == len[i] ? 0x80 : p >= rb * 64 - 8 ? uint8_t((len[i] * 8) >> (8 * (rb * 64 - 1 - p))) : 0;
+                if (r[p ^ 3] != want) { std::printf("raw mismatch round %d obj %d pos %llu\n", round, i, (unsigned long long)p); return 1; }
+            }
+            std::free(raw);
         }
         std::free(arena);
     }

@@ -193,6 +193,26 @@ def test_device_binning_gives_the_host_order(hasher):
     assert hasher.device_status() == 0
 
 
+def test_plain_sha1_of_buffers(hasher, oracle, golden_objects):
+    """vit_sha1_buffers: SHA1(data, len) with no Git framing, the reference's call (src/commit.cpp:93-94)
+    n at a time: FIPS 180 known answers, ragged buffers against hashlib, framed strings give object ids,
+    and a long buffer takes the host lane."""
+    for text, want in golden_objects["kats"]["sha1"]:
+        assert hasher.sha1_buffers([text.encode()])[0].tobytes().hex() == want
+    rng = np.random.default_rng(3)
+    lens = [0, 1, 55, 56, 63, 64, 65, 119, 120, 4096, 70_000, 3 << 20] + rng.integers(0, 5000, size=600).tolist()
+    bufs = [oracle.synth_bytes(50, i, L) for i, L in enumerate(lens)]
+    h0 = hasher.stat("objects_host")
+    got = hasher.sha1_buffers(bufs)
+    assert hasher.stat("objects_host") - h0 >= 1                       # the 3 MiB buffer
+    for i, b in enumerate(bufs):
+        assert got[i].tobytes() == hashlib.sha1(b).digest(), lens[i]
+    framed = [b"blob %d\0" % len(b) + b for b in bufs[:50]]
+    assert (hasher.sha1_buffers(framed) == hasher.hash_blobs(bufs[:50])).all()
+    hasher.set_option("host_threshold_bytes", 0)                       # every buffer on a GPU lane
+    assert (hasher.sha1_buffers(bufs) == got).all()
+
+
 def test_chunked_pipeline_matches_single_chunk(hasher, oracle):
     """Force many small staging chunks so both pinned buffers cycle several times."""
     lens = [(i * 37) % 5000 for i in range(3000)]

@@ -31,6 +31,7 @@ SIGNATURES = {
     "vit_object_blocks": (C.c_uint64, [C.c_char_p, C.c_uint64]),
     "vit_hash_objects": (C.c_int, [vp, C.c_char_p, vp, vp, C.c_uint64, vp]),
     "vit_hash_blobs": (C.c_int, [vp, vp, vp, C.c_uint64, vp]),
+    "vit_sha1_buffers": (C.c_int, [vp, vp, vp, C.c_uint64, vp]),
     "vit_host_object_id": (C.c_int, [C.c_char_p, vp, C.c_uint64, vp]),
     "vit_arena_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "vit_arena_free": (C.c_int, [vp, vp]),

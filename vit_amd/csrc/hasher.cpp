@@ -516,12 +516,28 @@ int vit_hasher_get_stat(const vit_hasher* h, const char* name, uint64_t* value)
     return VIT_OK;
 }
 
+// ids of n objects of one type, or (type == nullptr, tl == 0) plain SHA-1 of n buffers.
+static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_t* const* data, const uint64_t* len,
+                      uint64_t n, uint8_t* digests);
+
 int vit_hash_objects(vit_hasher* h, const char* type, const uint8_t* const* data, const uint64_t* len,
                      uint64_t n, uint8_t* digests)
 {
     if (!h) return VIT_ERR_ARG;
     const uint32_t tl = vit::type_len_checked(type);
     if (!tl) return fail(h, VIT_ERR_ARG, "bad object type");
+    return hash_batch(h, type, tl, data, len, n, digests);
+}
+
+int vit_sha1_buffers(vit_hasher* h, const uint8_t* const* data, const uint64_t* len, uint64_t n, uint8_t* digests)
+{
+    if (!h) return VIT_ERR_ARG;
+    return hash_batch(h, nullptr, 0, data, len, n, digests);
+}
+
+static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_t* const* data, const uint64_t* len,
+                      uint64_t n, uint8_t* digests)
+{
     if (n == 0) return VIT_OK;
     if (!data || !len || !digests) return fail(h, VIT_ERR_ARG, "null argument");
     if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 objects in one call");
@@ -567,7 +583,8 @@ int vit_hash_objects(vit_hasher* h, const char* type, const uint8_t* const* data
     uint64_t host_bytes = 0;
     for (uint64_t i = 0; i < n; ++i) {
         if (len[i] && !data[i]) return fail(h, VIT_ERR_ARG, "object %llu: null data with non-zero length", (unsigned long long)i);
-        const uint64_t b = (tl + 1 + vit::decimal_digits(len[i]) + 1 + len[i] + 9 + 63) / 64;
+        const uint64_t hl = tl ? tl + 1 + vit::decimal_digits(len[i]) + 1 : 0;
+        const uint64_t b = (hl + len[i] + 9 + 63) / 64;
         if (threshold && len[i] > threshold) { host_idx.push_back(i); host_bytes += len[i]; nb[i] = 0; continue; }
         if (b > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "object %llu too large for one lane", (unsigned long long)i);
         nb[i] = uint32_t(b);

@@ -32,6 +32,7 @@ uint32_t type_len_checked(const char* type)
 
 uint32_t write_header(const char* type, uint32_t tl, uint64_t len, uint8_t* out)
 {
+    if (tl == 0) return 0;                    // raw buffer: no Git framing
     std::memcpy(out, type, tl);
     out[tl] = ' ';
     const uint32_t nd = decimal_digits(len);

@@ -6,7 +6,8 @@ namespace vit {
 
 // strlen(type) if type is a usable object type name (1..8 bytes, no space), else 0.
 uint32_t type_len_checked(const char* type);
-// "<type> <len>\0" into out; returns the header length.
+// "<type> <len>\0" into out; returns the header length.  type_len 0 = a raw
+// buffer without Git framing: nothing is written, 0 is returned.
 uint32_t write_header(const char* type, uint32_t type_len, uint64_t len, uint8_t* out);
 // Header + content + SHA-1 padding into a slot of nblocks*64 bytes.
 void pack_one(const char* type, uint32_t type_len, const uint8_t* data, uint64_t len, uint8_t* slot,

@@ -141,10 +141,12 @@ void HostSha1::finish(uint8_t out[20])
 
 void host_object_id(const char* type, const uint8_t* content, uint64_t len, uint8_t out[20])
 {
-    char hdr[40];
-    int hl = std::snprintf(hdr, sizeof hdr, "%s %llu", type, static_cast<unsigned long long>(len)) + 1;
     HostSha1 s;
-    s.update(hdr, size_t(hl));
+    if (type) {                                           // nullptr: a raw buffer, no Git framing
+        char hdr[40];
+        int hl = std::snprintf(hdr, sizeof hdr, "%s %llu", type, static_cast<unsigned long long>(len)) + 1;
+        s.update(hdr, size_t(hl));
+    }
     s.update(content, size_t(len));
     s.finish(out);
 }

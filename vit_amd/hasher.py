@@ -178,6 +178,14 @@ class Hasher:
         self._check(self.lib.vit_hash_blobs(self.handle, ptrs, lens.ctypes.data, n, out.ctypes.data))
         return out[:n]
 
+    def sha1_buffers(self, buffers):
+        """Plain SHA-1 of each buffer (no Git framing)."""
+        keep, ptrs, lens = _as_ptr_arrays(buffers)
+        n = len(buffers)
+        out = np.zeros((max(n, 1), 20), dtype=np.uint8)
+        self._check(self.lib.vit_sha1_buffers(self.handle, ptrs, lens.ctypes.data, n, out.ctypes.data))
+        return out[:n]
+
     def hash_arena(self, arena, offsets, nblocks, dev=0, arena_bytes=None):
         arena = np.ascontiguousarray(arena, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
