@@ -81,7 +81,12 @@ int vit_hasher_device_count(const vit_hasher *h);
  *  "pack_threads"         host threads for packing and for the host lane
  *  "trace"                1: vit_hash_objects prints one line per staged
  *                         chunk to stderr (host and device timestamps of
- *                         pack, copy, kernel and read-back) */
+ *                         pack, copy, kernel and read-back)
+ *  "wave_trace_ptr"       diagnostics: a device address with room for 32 bytes
+ *                         per wave (4 waves per 256 objects); while it is set,
+ *                         every wave of a launch records there when it started
+ *                         and ended (100 MHz clock), its hardware id (SIMD, CU,
+ *                         SE, XCD) and its longest object in blocks; 0 = off */
 int vit_hasher_set_option(vit_hasher *h, const char *name, uint64_t value);
 
 /* Counters since creation: "objects_gpu", "objects_host", "bytes_host",

@@ -61,6 +61,8 @@ struct Queue {
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     void* sort_scratch = nullptr; size_t sort_scratch_bytes = 0;   // vit_bin_order_device
     std::vector<hipEvent_t> timing;                       // pool for vit_time_hash_device
+    uint64_t* wave_trace = nullptr;                       // diagnostics: device buffer, 32 bytes per wave, that the next
+                                                          // launches fill with their waves' timeline (tools/wave_timeline.py)
     std::string trace_log;                                // per-chunk timeline of the last call, when tracing
     clk::time_point trace_t0;
     Staging st[3];
@@ -198,10 +200,6 @@ void free_staging(Staging& s)
     s = Staging();
 }
 
-// Diagnostics, process-wide: a device buffer of 32 bytes per wave that the next launches fill with
-// their waves' timeline (tools/wave_timeline.py).
-uint64_t* g_wave_trace = nullptr;
-
 vit::DeviceBatch make_batch(const Queue& q, const void* d_arena, uint64_t arena_bytes, const uint64_t* d_off,
                             const uint32_t* d_nb, const uint32_t* d_order, uint64_t n, uint8_t* d_dig)
 {
@@ -212,7 +210,7 @@ vit::DeviceBatch make_batch(const Queue& q, const void* d_arena, uint64_t arena_
     b.n = uint32_t(n);
     b.digests = d_dig;
     b.status = q.d_status;
-    b.wave_trace = g_wave_trace;
+    b.wave_trace = q.wave_trace;
     return b;
 }
 
@@ -491,7 +489,7 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     else if (k == "chunk_bytes") h->chunk_bytes = value < (1u << 20) ? (1u << 20) : value;
     else if (k == "chunk_object_multiple") h->chunk_object_multiple = value;
     else if (k == "trace") h->trace = value != 0;
-    else if (k == "wave_trace_ptr") g_wave_trace = reinterpret_cast<uint64_t*>(uintptr_t(value));
+    else if (k == "wave_trace_ptr") { for (Queue& q : h->queues) q.wave_trace = reinterpret_cast<uint64_t*>(uintptr_t(value)); }
     else if (k == "pack_threads") h->pack_threads = value < 1 ? 1 : int(value > 256 ? 256 : value);
     else return fail(h, VIT_ERR_ARG, "unknown option '%s'", name);
     return VIT_OK;
