@@ -14,6 +14,8 @@ h = vit_amd.Hasher((0,))
 rng = np.random.default_rng(0x5EED0004)
 sizes = np.exp(rng.normal(np.log(4500.0), 1.55, n))
 sizes = np.minimum(sizes * (15000.0 / sizes.mean()), 262144).astype(np.uint64)
+if len(sys.argv) > 2 and sys.argv[2] == "uniform":
+    sizes[:] = 4096
 b = h.synth_arena("blob", 0x5EED0004, 0, n, 0, lens=sizes)
 nb = b["nblocks"].download(np.uint32, 4 * n)
 order_host, _ = vit_amd.bin_order(nb)
