@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Soak: random batches through vit_hash_blobs / vit_sha1_buffers under random pipeline settings
+(chunk sizes, host-lane thresholds, one or two queues on GPU 0, both kernels), every id compared with
+hashlib, for a given number of seconds.  Prints one JSON line; exits non-zero at the first mismatch."""
+import hashlib, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import vit_amd  # noqa: E402
+
+seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+pool = np.frombuffer(vit_amd.synth_bytes(99, seed, 64 << 20), dtype=np.uint8)
+hashers = [vit_amd.Hasher((0,)), vit_amd.Hasher((0, 0))]
+t_end = time.time() + seconds
+batches = objects = nbytes = 0
+while time.time() < t_end:
+    h = hashers[int(rng.integers(0, 2))]
+    h.set_option("kernel", int(rng.choice([0, 1, 5])))
+    h.set_option("chunk_bytes", int(rng.choice([1 << 20, 4 << 20, 64 << 20])))
+    h.set_option("chunk_object_multiple", int(rng.choice([0, 64, 8192])))
+    mode = int(rng.integers(0, 3))
+    if mode == 0:
+        h.set_option("host_auto", 1)
+    else:
+        h.set_option("host_threshold_bytes", int(rng.choice([0, 4096, 1 << 20])))
+    n = int(rng.choice([1, 7, 64, 65, 300, 5000, 40000]))
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        lens = rng.integers(0, 200, size=n)
+    elif kind == 1:
+        lens = rng.integers(0, 9000, size=n)
+    elif kind == 2:
+        lens = np.minimum(np.exp(rng.normal(np.log(3000.0), 1.8, n)), 6 << 20).astype(np.int64)
+    else:
+        lens = np.full(n, int(rng.choice([0, 55, 56, 64, 4096, 70000])))
+    if int(lens.sum()) > (1 << 30):
+        lens = lens // 8
+    starts = rng.integers(0, len(pool) - int(lens.max()) - 1, size=n)
+    bufs = [pool[int(s):int(s) + int(L)] for s, L in zip(starts, lens)]
+    raw = bool(rng.integers(0, 2))
+    got = h.sha1_buffers(bufs) if raw else h.hash_blobs(bufs)
+    check = range(n) if n <= 5000 else rng.choice(n, size=3000, replace=False)
+    for i in check:
+        b = bufs[int(i)].tobytes()
+        want = hashlib.sha1(b if raw else b"blob %d\0" % len(b) + b).digest()
+        if got[int(i)].tobytes() != want:
+            print(json.dumps({"mismatch": True, "batch": batches, "object": int(i), "len": len(b), "raw": raw, "n": n}))
+            sys.exit(1)
+    batches += 1; objects += n; nbytes += int(lens.sum())
+print(json.dumps({"seconds": seconds, "seed": seed, "batches": batches, "objects": objects, "GB": round(nbytes / 1e9, 2),
+                  "mismatches": 0}))
