@@ -39,7 +39,12 @@ while time.time() < t_end:
     starts = rng.integers(0, len(pool) - int(lens.max()) - 1, size=n)
     bufs = [pool[int(s):int(s) + int(L)] for s, L in zip(starts, lens)]
     raw = bool(rng.integers(0, 2))
-    got = h.sha1_buffers(bufs) if raw else h.hash_blobs(bufs)
+    if n <= 5000 and int(rng.integers(0, 4)) == 0:         # now and then: a pre-packed arena, 64- or 128-byte slots
+        raw = False
+        arena, off, nb, used = vit_amd.pack_arena("blob", bufs, slot_align=int(rng.choice([64, 128])), threads=3)
+        got = h.hash_arena(arena, off, nb, arena_bytes=used)
+    else:
+        got = h.sha1_buffers(bufs) if raw else h.hash_blobs(bufs)
     check = range(n) if n <= 5000 else rng.choice(n, size=3000, replace=False)
     for i in check:
         b = bufs[int(i)].tobytes()
