@@ -232,3 +232,26 @@ def test_git_order_with_symlinks_and_special_files_matches_live_git(oracle, tmp_
     for line in listing.splitlines():                     # every object git names is one we stored
         assert line.split()[2] in objs, line
     assert "120000" in listing and "100755" in listing and "hollow" not in listing
+
+
+def test_write_tree_flags_no_store_and_rewrite(golden_trees, worktrees, tmp_path):
+    """--no-store prints the id and writes nothing; a plain run then stores; a second plain run skips what
+    is there (already-stored = all of it); --rewrite writes every object again, as the reference always does."""
+    rec = golden_trees["nested_names"]
+    wt = fresh_copy(worktrees["nested_names"], tmp_path / "wt")
+    assert vit(wt, "write-tree", "--no-store").stdout.decode() == rec["root"] + "\n"
+    assert stored_objects(wt) == {}
+    assert vit(wt, "write-tree").stdout.decode() == rec["root"] + "\n"
+    objs = stored_objects(wt)
+    total = len(objs)
+    assert total == len(set(rec["tree_ids"]) | set(rec["blob_ids"]))
+    some = os.path.join(wt, ".git", "objects", rec["root"][:2], rec["root"][2:])
+    first = os.stat(some).st_ino
+    p = vit(wt, "write-tree", "--stats")
+    assert "already-stored %d" % (rec["n_blobs"] + len(rec["tree_ids"])) in p.stderr.decode() or \
+        "already-stored %d" % total in p.stderr.decode()
+    assert os.stat(some).st_ino == first                  # untouched
+    p = vit(wt, "write-tree", "--rewrite", "--stats")
+    assert p.stdout.decode() == rec["root"] + "\n" and "already-stored 0" in p.stderr.decode()
+    assert os.stat(some).st_ino != first                  # a new file was renamed into place
+    assert stored_objects(wt) == objs
