@@ -78,7 +78,20 @@ int vit_hasher_device_count(const vit_hasher *h);
  *                         object they may hold, up to 1 GiB
  *  "chunk_object_multiple" that growth: chunk = longest object x this
  *                         (default 8192; 0 = fixed chunk_bytes)
- *  "pack_threads"         host threads for packing and for the host lane
+ *  "pack_threads"         the host thread budget of a call: ONE pool of threads per
+ *                         hasher packs the chunks of every device queue (first) and
+ *                         hashes the host-lane objects (when no packing waits); the
+ *                         calling thread and the per-queue threads count against it,
+ *                         so the number of busy threads does not grow with the
+ *                         number of GPUs (default: the cores, at most 16)
+ *  "lane_rate" "core_rate" "copy_rate" "pack_rate"
+ *                         bytes per second of one GPU lane, one host core hashing,
+ *                         one pinned host-to-device copy and one host core packing:
+ *                         what "host_auto" balances with.  They are measured on this
+ *                         machine the first time a batch needs them (a few ms);
+ *                         setting one fixes it, 0 has it measured again
+ *  "debug_fail_at_chunk"  tests only: the N-th staged chunk of every later call fails
+ *                         as if a HIP call had (0 = off)
  *  "trace"                1: vit_hash_objects prints one line per staged
  *                         chunk to stderr (host and device timestamps of
  *                         pack, copy, kernel and read-back)
@@ -91,8 +104,11 @@ int vit_hasher_set_option(vit_hasher *h, const char *name, uint64_t value);
 
 /* Counters since creation: "objects_gpu", "objects_host", "bytes_host",
  * "blocks_gpu", "bytes_h2d", "launches"; of the last call: "last_kernel_ns",
- * "last_pack_ns", "last_total_ns", "last_host_threshold"; and
- * "host_sha_accelerated" (1 when the host lane uses the CPU's SHA extensions). */
+ * "last_pack_ns", "last_total_ns", "last_host_threshold" (shortest length moved to
+ * the host threads, less one), "last_host_objects"; the four rates above and
+ * "calibrate_ns" (what measuring them cost); "pool_threads", "pool_peak_busy"
+ * (most pool threads inside a task at once); and "host_sha_accelerated" (1 when
+ * the host lane uses the CPU's SHA extensions). */
 int vit_hasher_get_stat(const vit_hasher *h, const char *name, uint64_t *value);
 
 /* ---- framing (reference src/commit.cpp:90) ------------------------------- */
@@ -182,9 +198,16 @@ int vit_bin_order_device(vit_hasher *h, int dev, const uint32_t *d_nblocks, uint
  * reference is single-threaded and has no counterpart (src/commit.cpp:143). */
 int vit_shard_plan(const uint32_t *nblocks, uint64_t n, int n_queues, uint32_t *queue_of);
 
+/* Launch shape of the SHA-1 kernel for n objects (n <= 2^32 - 1): workgroups
+ * and threads per workgroup.  Host-only; lets the launch arithmetic be checked
+ * at sizes no test can allocate. */
+int vit_launch_shape(int kernel, uint64_t n, uint32_t *blocks, uint32_t *threads);
+
 /* Hash a packed arena that lives in host memory on device queue `dev`
  * (0 <= dev < vit_hasher_device_count).  Offsets and block counts are checked
- * against arena_bytes on the host before anything is launched. */
+ * against arena_bytes on the host before anything is launched.  An arena whose
+ * slots ascend (what vit_arena_pack writes) goes over in pieces of "chunk_bytes",
+ * the copy of one piece beside the kernel of the piece before. */
 int vit_hash_arena(vit_hasher *h, int dev, const void *arena, uint64_t arena_bytes,
                    const uint64_t *offsets, const uint32_t *nblocks, uint64_t n,
                    uint8_t *digests);
@@ -200,8 +223,10 @@ int vit_hash_arena_device(vit_hasher *h, int dev, const void *d_arena, uint64_t 
                           const uint32_t *d_order, uint64_t n, uint8_t *d_digests,
                           void *stream);
 
-/* Wait for queue `dev`, then read and clear its status word (0 = clean;
- * 1 out of bounds, 2 misaligned offset, 4 bad order entry). */
+/* Wait for queue `dev`'s own streams (a launch put on a caller's stream is the
+ * caller's to wait for first), then read and clear its status word (0 = clean;
+ * 1 out of bounds, 2 misaligned offset, 4 bad order entry).  No other stream of
+ * the device is stalled. */
 int vit_device_status(vit_hasher *h, int dev, uint32_t *status);
 
 /* ---- device memory, for callers without a HIP binding of their own -------- */

@@ -157,6 +157,20 @@ def test_shard_plan_balances_bytes_not_counts(lib):
     assert (np.diff(plan.astype(np.int64)) >= 0).all()
 
 
+def test_launch_shape_does_not_wrap_at_the_top_of_the_object_range(lib):
+    """The ABI admits n up to 2^32 - 1; the launch arithmetic must cover every object there
+    (n + 63 and n + 255 wrap in 32 bits for the last values of n)."""
+    blocks, threads = C.c_uint32(0), C.c_uint32(0)
+    for kernel in range(6):
+        for n in (1, 63, 64, 65, 255, 256, 257, 1_000_000, 0xFFFFFF00, 0xFFFFFFC0, 0xFFFFFFC1, 0xFFFFFFFF):
+            assert lib.vit_launch_shape(kernel, n, C.byref(blocks), C.byref(threads)) == 0
+            assert threads.value in (64, 128, 256)
+            lanes = blocks.value * threads.value
+            assert lanes >= n and lanes - n < threads.value, (kernel, n, blocks.value, threads.value)
+    assert lib.vit_launch_shape(0, 1 << 32, C.byref(blocks), C.byref(threads)) == -1
+    assert lib.vit_launch_shape(9, 5, C.byref(blocks), C.byref(threads)) == -1
+
+
 def test_host_lane_sha1_matches_reference_golden(lib, oracle, golden_objects):
     g = golden_objects["blobs"]
     for L, want in g["ids"]:

@@ -3,20 +3,25 @@
 // Host pipeline of vit_hash_objects(), per device queue:
 //
 //   pack chunk k+1 into pinned arena B   |  H2D copy, kernel, digest D2H of
-//   (header, content, padding; threads)  |  chunk k from pinned arena A (stream)
+//   (header, content, padding; pool)     |  chunk k from pinned arena A (stream)
 //
 // Two staging sets per queue alternate, so host packing overlaps the copy
 // engine and the kernel; a third set and stream carry the chunks of long
 // objects, and the longest objects of a skewed batch are hashed by host
-// threads meanwhile (see vit_hash_objects).  Objects are assigned to queues by
+// threads meanwhile (see hash_batch).  Objects are assigned to queues by
 // padded size (bytes), not by count; nothing is exchanged between devices
 // because every digest depends on its own object only and the consumer of the
 // digests (tree assembly, reference src/commit.cpp:164-172) runs on the host.
+//
+// Host threads: ONE pool per hasher (work_pool.h) serves the packing of every
+// queue's chunks (high priority) and the host-lane objects (low priority); a
+// queue's own thread only submits work and helps with its own packing.
 #include "../../include/vit_hash.h"
 #include "host_util.h"
 #include "kernels.h"
 #include "packer.h"
 #include "sha1_host.h"
+#include "work_pool.h"
 
 #include <hip/hip_runtime.h>
 
@@ -25,6 +30,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -47,17 +53,23 @@ struct Staging {
     uint64_t* d_off = nullptr;    uint32_t* d_nb = nullptr;  uint32_t* d_order = nullptr;  uint8_t* d_dig = nullptr;
     uint8_t*  h_meta = nullptr;   uint8_t* d_meta = nullptr;   // the two allocations the eight pointers above point into
     uint64_t  m_cap = 0;                                  // objects the meta buffers hold
+    uint32_t* h_status = nullptr;                         // pinned word behind the meta arrays: the queue's status word
+                                                          // as it stood after this chunk's kernel
     hipEvent_t done = nullptr;
     hipEvent_t mark[4] = {nullptr, nullptr, nullptr, nullptr};   // trace only: before copy, after copy, after kernel, after read-back
     double host_ms[4] = {0, 0, 0, 0};                            // trace only: submit begin, previous chunk retired, packed, queued
     bool in_flight = false, traced = false;
-    std::vector<uint64_t> obj;                            // caller indices of the chunk in flight
+    std::vector<uint64_t> obj;                            // caller indices of the chunk in flight; when empty, the chunk is
+    uint64_t first = 0, count = 0;                        // caller objects [first, first + count)
 };
 
 struct Queue {
     int device = 0;
     hipStream_t stream[3] = {nullptr, nullptr, nullptr};   // [0],[1]: alternating chunks; [2]: long objects
-    uint32_t* d_status = nullptr;
+    uint32_t* d_status = nullptr;                          // device: word 0 = STATUS_* bits; bytes 1024.. = calibration output
+    uint32_t* h_status = nullptr;                          // pinned: where vit_device_status reads that word to
+    uint32_t  status_seen = 0;                             // bits the chunks of host-memory calls have brought back
+    uint64_t  chunks_this_call = 0;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     void* sort_scratch = nullptr; size_t sort_scratch_bytes = 0;   // vit_bin_order_device
     std::vector<hipEvent_t> timing;                       // pool for vit_time_hash_device
@@ -69,6 +81,9 @@ struct Queue {
     std::string err;                                      // set by the queue's worker thread
 };
 
+constexpr uint64_t kStatusBytes = 4096;                   // allocation behind Queue::d_status
+constexpr uint64_t kCalibOut = 1024;                      // byte offset of the calibration kernel's output in it
+
 }  // namespace
 
 struct vit_hasher {
@@ -76,15 +91,23 @@ struct vit_hasher {
     mutable std::string err;
     int kernel = VIT_KERNEL_LDS;
     // Which objects go to host threads instead of a GPU lane: 0 never, 1 auto
-    // (threshold derived from the batch, see vit_hash_objects), 2 fixed threshold.
+    // (balanced per batch, see hash_batch), 2 fixed threshold.
     int host_policy = 1;
     uint64_t host_threshold = 0;
     uint64_t chunk_bytes = 64ull << 20;
     uint64_t chunk_object_multiple = 8192;
     bool trace = false;
-    int pack_threads = 8;
+    int pack_threads = 8;                                 // the host thread budget of a call, helpers included
+    std::unique_ptr<vit::WorkPool> pool;
+    // Rates the auto policy balances with, bytes per second; 0 = not measured
+    // yet.  *_fixed: set through an option, never measured.
+    double lane_rate = 0, core_rate = 0, copy_rate = 0, pack_rate = 0;
+    bool lane_fixed = false, core_fixed = false, copy_fixed = false, pack_fixed = false;
+    bool calibrated = false;
+    uint64_t calibrate_ns = 0;
+    uint64_t fail_at_chunk = 0;                           // fault injection for tests: 0 = off
     std::atomic<uint64_t> objects_gpu{0}, objects_host{0}, bytes_host{0}, blocks_gpu{0}, bytes_h2d{0}, launches{0};
-    uint64_t last_host_threshold = 0;
+    uint64_t last_host_threshold = 0, last_host_objects = 0;
     uint64_t last_kernel_ns = 0, last_pack_ns = 0, last_total_ns = 0;
 };
 
@@ -141,24 +164,47 @@ Queue* queue_of(vit_hasher* h, int dev)
 
 uint64_t round_up(uint64_t v, uint64_t q) { return (v + q - 1) / q * q; }
 
-int ensure_arena(Queue& q, Staging& s, uint64_t bytes)
+// Worker threads of the shared pool: the thread budget less the threads that
+// help from outside it (the caller with one queue, the queue threads with more).
+int pool_threads_for(const vit_hasher* h)
 {
-    if (bytes <= s.h_cap && bytes <= s.d_cap) return VIT_OK;
-    // Freeing and re-allocating staging costs milliseconds: start at 8 MiB and at least double.
-    const uint64_t want = std::max<uint64_t>({bytes, 8ull << 20, std::min<uint64_t>(2 * s.h_cap, 1ull << 30)});
-    const uint64_t cap = round_up(want, 1ull << 20);
-    if (s.h_arena) { HIP_TRYQ(q, hipHostFree(s.h_arena)); s.h_arena = nullptr; s.h_cap = 0; }
+    const int helpers = h->queues.size() > 1 ? int(h->queues.size()) : 1;
+    return std::max(1, h->pack_threads - helpers);
+}
+
+// Staging capacity: freeing and re-allocating costs milliseconds, so start at
+// 8 MiB and at least double.
+uint64_t grown(uint64_t have, uint64_t bytes)
+{
+    const uint64_t want = std::max<uint64_t>({bytes, 8ull << 20, std::min<uint64_t>(2 * have, 1ull << 30)});
+    return round_up(want, 1ull << 20);
+}
+
+int ensure_device_arena(Queue& q, Staging& s, uint64_t bytes)
+{
+    if (bytes <= s.d_cap) return VIT_OK;
+    const uint64_t cap = grown(s.d_cap, bytes);
     if (s.d_arena) { HIP_TRYQ(q, hipFree(s.d_arena)); s.d_arena = nullptr; s.d_cap = 0; }
-    HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_arena), cap, hipHostMallocDefault));
-    s.h_cap = cap;
     HIP_TRYQ(q, hipMalloc(reinterpret_cast<void**>(&s.d_arena), cap));
     s.d_cap = cap;
     return VIT_OK;
 }
 
+int ensure_arena(Queue& q, Staging& s, uint64_t bytes)
+{
+    if (bytes > s.h_cap) {
+        const uint64_t cap = grown(s.h_cap, bytes);
+        if (s.h_arena) { HIP_TRYQ(q, hipHostFree(s.h_arena)); s.h_arena = nullptr; s.h_cap = 0; }
+        HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_arena), cap, hipHostMallocDefault));
+        s.h_cap = cap;
+    }
+    return ensure_device_arena(q, s, bytes);
+}
+
 // Offsets, block counts, order and digests of a chunk live in ONE pinned and ONE
 // device allocation (36 bytes per object): allocations cost about a millisecond
-// each, which is most of a small first call.
+// each, which is most of a small first call.  The pinned one ends with the word
+// the chunk's copy of the device status lands in.
 int ensure_meta(Queue& q, Staging& s, uint64_t n)
 {
     if (n <= s.m_cap) return VIT_OK;
@@ -166,8 +212,10 @@ int ensure_meta(Queue& q, Staging& s, uint64_t n)
     if (s.h_meta) { HIP_TRYQ(q, hipHostFree(s.h_meta)); s.h_meta = nullptr; }
     if (s.d_meta) { HIP_TRYQ(q, hipFree(s.d_meta)); s.d_meta = nullptr; }
     s.m_cap = 0;
-    HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_meta), cap * 36, hipHostMallocDefault));
+    HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_meta), cap * 36 + 64, hipHostMallocDefault));
     HIP_TRYQ(q, hipMalloc(reinterpret_cast<void**>(&s.d_meta), cap * 36));
+    s.h_status = reinterpret_cast<uint32_t*>(s.h_meta + cap * 36);
+    *s.h_status = 0;
     s.m_cap = cap;
     return VIT_OK;
 }
@@ -214,12 +262,15 @@ vit::DeviceBatch make_batch(const Queue& q, const void* d_arena, uint64_t arena_
     return b;
 }
 
-// Collect a finished chunk: wait for it and scatter its digests to the caller.
+// Collect a finished chunk: wait for it, scatter its digests to the caller and
+// note the status word it brought back.
 int retire(Queue& q, Staging& s, uint8_t* digests)
 {
     if (!s.in_flight) return VIT_OK;
     HIP_TRYQ(q, hipEventSynchronize(s.done));
-    for (size_t i = 0; i < s.obj.size(); ++i) std::memcpy(digests + s.obj[i] * 20, s.h_dig + i * 20, 20);
+    if (s.obj.empty()) std::memcpy(digests + s.first * 20, s.h_dig, s.count * 20);
+    else for (size_t i = 0; i < s.obj.size(); ++i) std::memcpy(digests + s.obj[i] * 20, s.h_dig + i * 20, 20);
+    q.status_seen |= *s.h_status;
     s.in_flight = false;
     if (s.traced) {
         float g[4] = {0, 0, 0, 0};
@@ -228,11 +279,25 @@ int retire(Queue& q, Staging& s, uint8_t* digests)
         std::snprintf(line, sizeof line,
                       "set %d objs %8zu | host ms: begin %8.2f retired-prev %8.2f packed %8.2f queued %8.2f collected %8.2f"
                       " | gpu ms: copy %8.2f..%8.2f kernel ..%8.2f read-back ..%8.2f\n",
-                      int(&s - q.st), s.obj.size(), s.host_ms[0], s.host_ms[1], s.host_ms[2], s.host_ms[3],
-                      double(ns_since(q.trace_t0)) * 1e-6, g[0], g[1], g[2], g[3]);
+                      int(&s - q.st), s.obj.empty() ? size_t(s.count) : s.obj.size(), s.host_ms[0], s.host_ms[1],
+                      s.host_ms[2], s.host_ms[3], double(ns_since(q.trace_t0)) * 1e-6, g[0], g[1], g[2], g[3]);
         q.trace_log += line;
     }
     return VIT_OK;
+}
+
+// Forget whatever an earlier call left in flight on this queue (a call that
+// failed midway returns with chunks still queued): wait for the streams and
+// drop the chunks WITHOUT delivering their digests, whose destination belonged
+// to that earlier call.
+void drain(Queue& q)
+{
+    bool any = false;
+    for (const Staging& s : q.st) any = any || s.in_flight;
+    if (!any) return;
+    (void)hipSetDevice(q.device);
+    for (hipStream_t st : q.stream) if (st) (void)hipStreamSynchronize(st);
+    for (Staging& s : q.st) { s.in_flight = false; s.obj.clear(); s.count = 0; }
 }
 
 struct Job {
@@ -243,6 +308,28 @@ struct Job {
     uint8_t* digests;
 };
 
+// Queue copy, kernel, digest and status read-back of a chunk whose arena bytes
+// [0, bytes) are at `src` in pinned (or at least host) memory.
+int launch_chunk(Queue& q, vit_hasher* h, Staging& s, hipStream_t stream, const uint8_t* src, uint64_t bytes,
+                 uint64_t meta_bytes, bool binned, uint64_t cnt, bool trace)
+{
+    if (trace) { s.host_ms[2] = double(ns_since(q.trace_t0)) * 1e-6; HIP_TRYQ(q, hipEventRecord(s.mark[0], stream)); }
+    HIP_TRYQ(q, hipMemcpyAsync(s.d_arena, src, bytes, hipMemcpyHostToDevice, stream));
+    HIP_TRYQ(q, hipMemcpyAsync(s.d_meta, s.h_meta, meta_bytes + (binned ? meta_bytes / 3 : 0), hipMemcpyHostToDevice, stream));
+    if (trace) HIP_TRYQ(q, hipEventRecord(s.mark[1], stream));
+    HIP_TRYQ(q, vit::launch_sha1(vit::KernelVariant(h->kernel),
+                                 make_batch(q, s.d_arena, bytes, s.d_off, s.d_nb, binned ? s.d_order : nullptr, cnt,
+                                            s.d_dig),
+                                 stream));
+    if (trace) HIP_TRYQ(q, hipEventRecord(s.mark[2], stream));
+    HIP_TRYQ(q, hipMemcpyAsync(s.h_dig, s.d_dig, cnt * 20, hipMemcpyDeviceToHost, stream));
+    HIP_TRYQ(q, hipMemcpyAsync(s.h_status, q.d_status, 4, hipMemcpyDeviceToHost, stream));
+    if (trace) { HIP_TRYQ(q, hipEventRecord(s.mark[3], stream)); s.host_ms[3] = double(ns_since(q.trace_t0)) * 1e-6; }
+    HIP_TRYQ(q, hipEventRecord(s.done, stream));
+    s.in_flight = true;
+    return VIT_OK;
+}
+
 // Pack one chunk (objects idx[0..cnt)) into staging set s and queue its copy,
 // kernel and digest read-back on `stream`.
 int submit_chunk(Queue& q, const Job& job, Staging& s, hipStream_t stream, const uint64_t* idx, uint64_t cnt,
@@ -252,6 +339,10 @@ int submit_chunk(Queue& q, const Job& job, Staging& s, hipStream_t stream, const
     const double begin_ms = double(ns_since(q.trace_t0)) * 1e-6;
     int rc = retire(q, s, job.digests);
     if (rc) return rc;
+    if (h->fail_at_chunk && ++q.chunks_this_call == h->fail_at_chunk) {
+        q.err = "failure injected at chunk " + std::to_string(q.chunks_this_call) + " (option debug_fail_at_chunk)";
+        return VIT_ERR_HIP;
+    }
     if (h->trace) {
         for (hipEvent_t& m : s.mark) if (!m) HIP_TRYQ(q, hipEventCreate(&m));
         s.host_ms[0] = begin_ms;
@@ -267,36 +358,32 @@ int submit_chunk(Queue& q, const Job& job, Staging& s, hipStream_t stream, const
 
     const auto t0 = clk::now();
     s.obj.assign(idx, idx + cnt);
+    s.first = s.count = 0;
     std::vector<uint64_t> prefix(cnt + 1, 0);
     for (uint64_t i = 0; i < cnt; ++i) {
         s.h_off[i] = prefix[i] * 64;
         s.h_nb[i] = job.nb[idx[i]];
         prefix[i + 1] = prefix[i] + s.h_nb[i];
     }
-    const int threads = bytes < (4u << 20) ? 1 : h->pack_threads;
-    vit::parallel_ranges(cnt, threads, prefix.data(), [&](int, uint64_t b, uint64_t e) {
+    auto pack_range = [&](uint64_t b, uint64_t e) {
         for (uint64_t i = b; i < e; ++i) {
             const uint64_t o = idx[i];
             vit::pack_one(job.type, job.tl, job.data[o], job.len[o], s.h_arena + s.h_off[i], s.h_nb[i]);
         }
         vit::pack_fence();
-    });
+    };
+    // Pieces of about 2 MiB, at most four per thread of the budget: short enough
+    // that the pool's threads even out, long enough that claiming one is free.
+    const uint64_t pieces = std::min<uint64_t>({cnt, bytes / (2u << 20), uint64_t(h->pack_threads) * 4});
+    if (pieces <= 1) pack_range(0, cnt);
+    else {
+        const std::vector<uint64_t> cut = vit::balanced_cuts(cnt, int(pieces), prefix.data());
+        h->pool->run(vit::WorkPool::HIGH, size_t(pieces), [&](size_t p) { if (cut[p] < cut[p + 1]) pack_range(cut[p], cut[p + 1]); });
+    }
     const bool binned = vit::bin_order(s.h_nb, cnt, s.h_order);
     *pack_ns += ns_since(t0);
 
-    if (trace) { s.host_ms[2] = double(ns_since(q.trace_t0)) * 1e-6; HIP_TRYQ(q, hipEventRecord(s.mark[0], stream)); }
-    HIP_TRYQ(q, hipMemcpyAsync(s.d_arena, s.h_arena, bytes, hipMemcpyHostToDevice, stream));
-    HIP_TRYQ(q, hipMemcpyAsync(s.d_meta, s.h_meta, meta_bytes + (binned ? meta_bytes / 3 : 0), hipMemcpyHostToDevice, stream));
-    if (trace) HIP_TRYQ(q, hipEventRecord(s.mark[1], stream));
-    HIP_TRYQ(q, vit::launch_sha1(vit::KernelVariant(h->kernel),
-                                 make_batch(q, s.d_arena, bytes, s.d_off, s.d_nb, binned ? s.d_order : nullptr, cnt,
-                                            s.d_dig),
-                                 stream));
-    if (trace) HIP_TRYQ(q, hipEventRecord(s.mark[2], stream));
-    HIP_TRYQ(q, hipMemcpyAsync(s.h_dig, s.d_dig, cnt * 20, hipMemcpyDeviceToHost, stream));
-    if (trace) { HIP_TRYQ(q, hipEventRecord(s.mark[3], stream)); s.host_ms[3] = double(ns_since(q.trace_t0)) * 1e-6; }
-    HIP_TRYQ(q, hipEventRecord(s.done, stream));
-    s.in_flight = true;
+    if ((rc = launch_chunk(q, h, s, stream, s.h_arena, bytes, meta_bytes, binned, cnt, trace))) return rc;
     h->objects_gpu += cnt; h->blocks_gpu += blocks; h->bytes_h2d += bytes + cnt * 16; ++h->launches;
     return VIT_OK;
 }
@@ -307,13 +394,13 @@ int submit_chunk(Queue& q, const Job& job, Staging& s, hipStream_t stream, const
 // chunks stream past them on the other two.
 constexpr uint32_t kLongBlocks = 4096;
 
-// Hash the objects `mine` (caller indices, in order) on queue q.
-int run_queue(Queue& q, const Job& job, const std::vector<uint64_t>& mine, uint64_t* pack_ns)
+int run_queue_body(Queue& q, const Job& job, const std::vector<uint64_t>& mine, uint64_t* pack_ns)
 {
     vit_hasher* h = job.h;
     HIP_TRYQ(q, hipSetDevice(q.device));
     q.trace_t0 = clk::now();
     q.trace_log.clear();
+    q.chunks_this_call = 0;
     if (h->trace) HIP_TRYQ(q, hipEventRecord(q.ev_a, q.stream[0]));
     std::vector<uint64_t> longs, rest;
     for (uint64_t i : mine) (job.nb[i] >= kLongBlocks ? longs : rest).push_back(i);
@@ -373,6 +460,18 @@ int run_queue(Queue& q, const Job& job, const std::vector<uint64_t>& mine, uint6
     return VIT_OK;
 }
 
+// Hash the objects `mine` (caller indices, in order) on queue q.  However it
+// ends, nothing stays in flight on the queue.
+int run_queue(Queue& q, const Job& job, const std::vector<uint64_t>& mine, uint64_t* pack_ns)
+{
+    int rc;
+    try { rc = run_queue_body(q, job, mine, pack_ns); }
+    catch (const std::bad_alloc&) { q.err = "out of host memory"; rc = VIT_ERR_NOMEM; }
+    catch (const std::exception& e) { q.err = e.what(); rc = VIT_ERR_HIP; }
+    if (rc != VIT_OK) drain(q);
+    return rc;
+}
+
 // Split object indices over the queues by padded size: the few objects that
 // are large against a fair share go greedily to the least loaded queue, the
 // rest fill the queues in index order up to the fair share.
@@ -399,6 +498,94 @@ void shard(const std::vector<uint64_t>& idx, const uint32_t* nb, size_t nq, std:
     for (auto& v : out) std::sort(v.begin(), v.end());
 }
 
+// Read the queue's device status word through its first stream and clear it if set.
+int read_status_word(vit_hasher* h, Queue& q, uint32_t* out)
+{
+    HIP_TRY(h, hipMemcpyAsync(q.h_status, q.d_status, 4, hipMemcpyDeviceToHost, q.stream[0]));
+    HIP_TRY(h, hipStreamSynchronize(q.stream[0]));
+    *out = *q.h_status;
+    if (*out) {
+        HIP_TRY(h, hipMemsetAsync(q.d_status, 0, 4, q.stream[0]));
+        HIP_TRY(h, hipStreamSynchronize(q.stream[0]));
+    }
+    return VIT_OK;
+}
+
+// Measure, once per hasher and on its first queue, the four rates the auto
+// policy balances with (anything set through an option stays as set):
+//   core_rate  one host thread's SHA-1 (vit::host_object_id over 4 MiB)
+//   pack_rate  one host thread packing into a pinned staging arena (4 MiB)
+//   copy_rate  one pinned host-to-device copy (32 MiB)
+//   lane_rate  one GPU lane: a lone wave running 1024 compressions back to back,
+//              times 0.8: with four other waves resident, the SIMD's oldest wave
+//              (a long object's wave always is) gets about that share of issue
+//              (1.15 us per block alone, 1.4 to 1.5 us in a full launch).
+int calibrate(vit_hasher* h)
+{
+    if (h->calibrated) return VIT_OK;
+    const auto t0 = clk::now();
+    Queue& q = h->queues[0];
+    HIP_TRY(h, hipSetDevice(q.device));
+    constexpr uint64_t kHost = 4ull << 20, kCopy = 32ull << 20;
+    std::vector<uint8_t> src(kHost, 0x5A);
+    if (!h->core_fixed) {
+        double best = 1e30;
+        uint8_t d[20];
+        for (int r = 0; r < 2; ++r) {
+            const auto t = clk::now();
+            vit::host_object_id("blob", src.data(), kHost, d);
+            best = std::min(best, double(ns_since(t)) * 1e-9);
+        }
+        h->core_rate = double(kHost) / best;
+    }
+    if (!h->pack_fixed || !h->copy_fixed) {
+        Staging& s = q.st[0];
+        if (ensure_arena(q, s, kCopy) != VIT_OK) return fail(h, VIT_ERR_NOMEM, "calibration: %s", q.err.c_str());
+        if (!h->pack_fixed) {
+            const uint64_t len = kHost - 64, nb = (4 + 1 + 7 + 1 + len + 9 + 63) / 64;
+            double best = 1e30;
+            for (int r = 0; r < 2; ++r) {
+                const auto t = clk::now();
+                vit::pack_one("blob", 4, src.data(), len, s.h_arena, nb);
+                vit::pack_fence();
+                best = std::min(best, double(ns_since(t)) * 1e-9);
+            }
+            h->pack_rate = double(len) / best;
+        }
+        if (!h->copy_fixed) {
+            float best = 1e30f;
+            for (int r = 0; r < 2; ++r) {
+                HIP_TRY(h, hipEventRecord(q.ev_a, q.stream[0]));
+                HIP_TRY(h, hipMemcpyAsync(s.d_arena, s.h_arena, kCopy, hipMemcpyHostToDevice, q.stream[0]));
+                HIP_TRY(h, hipEventRecord(q.ev_b, q.stream[0]));
+                HIP_TRY(h, hipEventSynchronize(q.ev_b));
+                float ms = 0;
+                HIP_TRY(h, hipEventElapsedTime(&ms, q.ev_a, q.ev_b));
+                best = std::min(best, ms);
+            }
+            h->copy_rate = double(kCopy) / (double(best) * 1e-3);
+        }
+    }
+    if (!h->lane_fixed) {
+        constexpr uint32_t kBlocks = 1024;
+        uint32_t* out = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(q.d_status) + kCalibOut);
+        float best = 1e30f;
+        for (int r = 0; r < 3; ++r) {                     // the first launch loads the code object
+            HIP_TRY(h, hipEventRecord(q.ev_a, q.stream[0]));
+            HIP_TRY(h, vit::launch_valu_peak(out, 64, kBlocks, q.stream[0]));
+            HIP_TRY(h, hipEventRecord(q.ev_b, q.stream[0]));
+            HIP_TRY(h, hipEventSynchronize(q.ev_b));
+            float ms = 0;
+            HIP_TRY(h, hipEventElapsedTime(&ms, q.ev_a, q.ev_b));
+            if (r) best = std::min(best, ms);
+        }
+        h->lane_rate = 0.8 * double(kBlocks) * 64.0 / (double(best) * 1e-3);
+    }
+    h->calibrated = true;
+    h->calibrate_ns = ns_since(t0);
+    return VIT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -418,9 +605,15 @@ int vit_hasher_create(const int* device_ids, int n_devices, vit_hasher** out)
 
     vit_hasher* h = new (std::nothrow) vit_hasher();
     if (!h) return fail(nullptr, VIT_ERR_NOMEM, "out of host memory");
-    h->queues.resize(ids.size());
-    unsigned hw = std::thread::hardware_concurrency();
-    h->pack_threads = int(hw ? (hw > 16 ? 16 : hw) : 4);
+    try {
+        h->queues.resize(ids.size());
+        unsigned hw = std::thread::hardware_concurrency();
+        h->pack_threads = int(hw ? (hw > 16 ? 16 : hw) : 4);
+        h->pool.reset(new vit::WorkPool(pool_threads_for(h)));
+    } catch (const std::exception&) {
+        delete h;
+        return fail(nullptr, VIT_ERR_NOMEM, "out of host memory");
+    }
     for (size_t k = 0; k < ids.size(); ++k) {
         Queue& q = h->queues[k];
         q.device = ids[k];
@@ -434,8 +627,12 @@ int vit_hasher_create(const int* device_ids, int n_devices, vit_hasher** out)
         if (r == hipSuccess) r = hipSetDevice(ids[k]);
         for (hipStream_t& st : q.stream)
             if (r == hipSuccess) r = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
-        if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void**>(&q.d_status), 256);
-        if (r == hipSuccess) r = hipMemset(q.d_status, 0, 256);
+        if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void**>(&q.d_status), kStatusBytes);
+        if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void**>(&q.h_status), 64, hipHostMallocDefault);
+        // The kernels run on non-blocking streams, which the null stream does not
+        // order with: clear the word on the stream that will use it, and wait.
+        if (r == hipSuccess) r = hipMemsetAsync(q.d_status, 0, kStatusBytes, q.stream[0]);
+        if (r == hipSuccess) r = hipStreamSynchronize(q.stream[0]);
         if (r == hipSuccess) r = hipEventCreate(&q.ev_a);
         if (r == hipSuccess) r = hipEventCreate(&q.ev_b);
         // Timing events are made here so that a timed run creates none.
@@ -464,6 +661,7 @@ void vit_hasher_destroy(vit_hasher* h)
         for (hipStream_t st : q.stream) if (st) (void)hipStreamSynchronize(st);
         for (Staging& s : q.st) free_staging(s);
         if (q.d_status) (void)hipFree(q.d_status);
+        if (q.h_status) (void)hipHostFree(q.h_status);
         if (q.ev_a) (void)hipEventDestroy(q.ev_a);
         if (q.ev_b) (void)hipEventDestroy(q.ev_b);
         if (q.sort_scratch) (void)hipFree(q.sort_scratch);
@@ -480,7 +678,9 @@ int vit_hasher_device_count(const vit_hasher* h) { return h ? int(h->queues.size
 int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
 {
     if (!h || !name) return VIT_ERR_ARG;
+    VIT_NOEXCEPT_BEGIN
     const std::string k(name);
+    auto rate = [&](double& r, bool& fixed) { r = double(value); fixed = value != 0; if (!value) h->calibrated = false; };
     if (k == "kernel") {
         if (value > 5) return fail(h, VIT_ERR_ARG, "unknown kernel %llu", (unsigned long long)value);
         h->kernel = int(value);
@@ -490,9 +690,18 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     else if (k == "chunk_object_multiple") h->chunk_object_multiple = value;
     else if (k == "trace") h->trace = value != 0;
     else if (k == "wave_trace_ptr") { for (Queue& q : h->queues) q.wave_trace = reinterpret_cast<uint64_t*>(uintptr_t(value)); }
-    else if (k == "pack_threads") h->pack_threads = value < 1 ? 1 : int(value > 256 ? 256 : value);
+    else if (k == "pack_threads") {
+        h->pack_threads = value < 1 ? 1 : int(value > 256 ? 256 : value);
+        h->pool->resize(pool_threads_for(h));
+    }
+    else if (k == "lane_rate") rate(h->lane_rate, h->lane_fixed);
+    else if (k == "core_rate") rate(h->core_rate, h->core_fixed);
+    else if (k == "copy_rate") rate(h->copy_rate, h->copy_fixed);
+    else if (k == "pack_rate") rate(h->pack_rate, h->pack_fixed);
+    else if (k == "debug_fail_at_chunk") h->fail_at_chunk = value;
     else return fail(h, VIT_ERR_ARG, "unknown option '%s'", name);
     return VIT_OK;
+    VIT_NOEXCEPT_END(h)
 }
 
 int vit_hasher_get_stat(const vit_hasher* h, const char* name, uint64_t* value)
@@ -503,6 +712,7 @@ int vit_hasher_get_stat(const vit_hasher* h, const char* name, uint64_t* value)
     else if (k == "objects_host") *value = h->objects_host;
     else if (k == "bytes_host") *value = h->bytes_host;
     else if (k == "last_host_threshold") *value = h->last_host_threshold;
+    else if (k == "last_host_objects") *value = h->last_host_objects;
     else if (k == "blocks_gpu") *value = h->blocks_gpu;
     else if (k == "bytes_h2d") *value = h->bytes_h2d;
     else if (k == "launches") *value = h->launches;
@@ -510,6 +720,13 @@ int vit_hasher_get_stat(const vit_hasher* h, const char* name, uint64_t* value)
     else if (k == "last_pack_ns") *value = h->last_pack_ns;
     else if (k == "last_total_ns") *value = h->last_total_ns;
     else if (k == "host_sha_accelerated") *value = vit::HostSha1::accelerated();
+    else if (k == "lane_rate") *value = uint64_t(h->lane_rate);
+    else if (k == "core_rate") *value = uint64_t(h->core_rate);
+    else if (k == "copy_rate") *value = uint64_t(h->copy_rate);
+    else if (k == "pack_rate") *value = uint64_t(h->pack_rate);
+    else if (k == "calibrate_ns") *value = h->calibrate_ns;
+    else if (k == "pool_threads") *value = uint64_t(h->pool->threads());
+    else if (k == "pool_peak_busy") *value = uint64_t(h->pool->peak_busy());
     else return fail(h, VIT_ERR_ARG, "unknown stat '%s'", name);
     return VIT_OK;
 }
@@ -538,71 +755,92 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
 {
     if (n == 0) return VIT_OK;
     if (!data || !len || !digests) return fail(h, VIT_ERR_ARG, "null argument");
-    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 objects in one call");
+    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 - 1 objects in one call");
     const auto t0 = clk::now();
     VIT_NOEXCEPT_BEGIN
+    for (Queue& q : h->queues) { drain(q); q.status_seen = 0; }
 
-    // One SHA-1 stream is serial: a lane sustains about 45 MB/s and a host core
-    // with SHA extensions about 1.8 GB/s, while a whole batch moves through
-    // pack + PCIe at about 40 GB/s per GPU.  The auto policy balances the two
-    // sides: starting from the longest object, an object of 64 KiB or more
-    // moves to the host threads as long as the host side (its bytes over the
-    // threads, never less than its longest object on one core) still finishes
-    // before the GPU side would with the object on it (transfer time of its
-    // bytes, never less than its longest object on one lane).  Packing is
-    // memory-bound and light, so the same threads carry both.
+    // Which objects leave the GPU.  One SHA-1 stream is serial: a lane sustains
+    // about 45 MB/s and a host core with SHA extensions about 2 GB/s, while a
+    // whole batch moves through pack + PCIe at about 40 GB/s per GPU.  The auto
+    // policy balances the two sides with rates measured on this machine
+    // (calibrate): starting from the longest object, an object of 64 KiB or more
+    // moves to the host threads as long as the host side still finishes before
+    // the GPU side would with the object on it.
+    //   GPU side:  its bytes through the queues (0.8 x the copy rate each, the
+    //              pipeline's measured efficiency, and no faster than the
+    //              threads can pack), never less than its longest object on one
+    //              lane;
+    //   host side: the thread-seconds of hashing the moved bytes AND of packing
+    //              the GPU side's bytes, over the thread budget (one pool carries
+    //              both), never less than the longest moved object on one core.
+    // Objects move one by one in (length, index) order, so a run of equal
+    // lengths may be split between the two sides.
+    std::vector<uint32_t> nb(n);
+    std::vector<uint64_t> gpu_idx, host_idx;
     uint64_t threshold = 0;
     if (h->host_policy == 2) threshold = h->host_threshold;
     else if (h->host_policy == 1) {
-        constexpr double kLaneRate = 45e6, kQueueRate = 40e9;
-        const double core_rate = vit::HostSha1::accelerated() ? 1.8e9 : 0.45e9;
-        const double host_rate = core_rate * double(h->pack_threads);
         uint64_t total = 0;
         std::vector<uint64_t> cand;
         for (uint64_t i = 0; i < n; ++i) {
             total += len[i];
-            if (len[i] >= (64u << 10)) cand.push_back(len[i]);
+            if (len[i] >= (64u << 10)) cand.push_back(i);
         }
-        std::sort(cand.begin(), cand.end(), std::greater<uint64_t>());
-        double gpu_bytes = double(total), host_bytes = 0;
-        for (uint64_t L : cand) {
-            const double gpu_time = std::max(gpu_bytes / (kQueueRate * double(h->queues.size())), double(L) / kLaneRate);
-            const double host_time = std::max((host_bytes + double(L)) / host_rate, double(cand[0]) / core_rate);
-            if (host_time >= gpu_time) break;
-            gpu_bytes -= double(L); host_bytes += double(L);
-            threshold = L - 1;
+        if (!cand.empty()) {
+            if (int rc = calibrate(h)) return rc;
+            std::stable_sort(cand.begin(), cand.end(), [&](uint64_t a, uint64_t b) { return len[a] > len[b]; });
+            const double threads = double(h->pack_threads);
+            const double queue_rate = std::min(0.8 * h->copy_rate * double(h->queues.size()), h->pack_rate * threads);
+            const double longest = double(len[cand[0]]);
+            double gpu_bytes = double(total), host_bytes = 0;
+            size_t moved = 0;
+            for (uint64_t i : cand) {
+                const double L = double(len[i]);
+                const double gpu_time = std::max(gpu_bytes / queue_rate, L / h->lane_rate);
+                const double host_time = std::max(((host_bytes + L) / h->core_rate + (gpu_bytes - L) / h->pack_rate) / threads,
+                                                  longest / h->core_rate);
+                if (host_time >= gpu_time) break;
+                gpu_bytes -= L; host_bytes += L;
+                ++moved;
+            }
+            host_idx.assign(cand.begin(), cand.begin() + long(moved));
+            if (moved) threshold = len[cand[moved - 1]] - 1;
         }
     }
     h->last_host_threshold = threshold;
 
-    std::vector<uint32_t> nb(n);
-    std::vector<uint64_t> gpu_idx, host_idx;
-    gpu_idx.reserve(n);
     uint64_t host_bytes = 0;
+    if (h->host_policy == 2 && threshold)
+        for (uint64_t i = 0; i < n; ++i) if (len[i] > threshold) host_idx.push_back(i);
+    for (uint64_t i : host_idx) { nb[i] = 0xFFFFFFFFu; host_bytes += len[i]; }      // marker: not for a lane
+    gpu_idx.reserve(n - host_idx.size());
     for (uint64_t i = 0; i < n; ++i) {
         if (len[i] && !data[i]) return fail(h, VIT_ERR_ARG, "object %llu: null data with non-zero length", (unsigned long long)i);
+        if (!host_idx.empty() && nb[i] == 0xFFFFFFFFu) { nb[i] = 0; continue; }
         const uint64_t hl = tl ? tl + 1 + vit::decimal_digits(len[i]) + 1 : 0;
         const uint64_t b = (hl + len[i] + 9 + 63) / 64;
-        if (threshold && len[i] > threshold) { host_idx.push_back(i); host_bytes += len[i]; nb[i] = 0; continue; }
-        if (b > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "object %llu too large for one lane", (unsigned long long)i);
+        if (b >= 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "object %llu too large for one lane", (unsigned long long)i);
         nb[i] = uint32_t(b);
         gpu_idx.push_back(i);
     }
+    h->last_host_objects = host_idx.size();
 
-    // Oversized objects: one SHA-1 stream each on host threads, beside the GPU batch.
-    ThreadGroup host_workers;
-    std::atomic<size_t> next_host{0};
+    // Oversized objects: one SHA-1 stream each on the pool's threads, at low
+    // priority, beside the GPU batch; longest first, so the tail is short.
+    vit::WorkPool::Ticket host_work;
+    // From the submit below on, the pool's workers hold references into this
+    // frame: every path out waits for them first.
+    struct WaitHost {
+        vit::WorkPool& pool; vit::WorkPool::Ticket& t;
+        ~WaitHost() { if (t) pool.wait(t); }
+    } wait_host{*h->pool, host_work};
     if (!host_idx.empty()) {
-        // longest first, so the tail of the host work is short
         std::stable_sort(host_idx.begin(), host_idx.end(), [&](uint64_t a, uint64_t b) { return len[a] > len[b]; });
-        const size_t nt = std::min<size_t>(host_idx.size(), size_t(h->pack_threads));
-        for (size_t t = 0; t < nt; ++t)
-            host_workers.t.emplace_back([&] {
-                for (size_t k; (k = next_host++) < host_idx.size();) {
-                    const uint64_t i = host_idx[k];
-                    vit::host_object_id(type, data[i], len[i], digests + i * 20);
-                }
-            });
+        host_work = h->pool->submit(vit::WorkPool::LOW, host_idx.size(), [&](size_t k) {
+            const uint64_t i = host_idx[k];
+            vit::host_object_id(type, data[i], len[i], digests + i * 20);
+        });
         h->objects_host += host_idx.size();
         h->bytes_host += host_bytes;
     }
@@ -617,13 +855,11 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
     } else {
         ThreadGroup workers;
         for (size_t k = 0; k < h->queues.size(); ++k)
-            workers.t.emplace_back([&, k] {
-                try { rcs[k] = run_queue(h->queues[k], job, parts[k], &pack_ns[k]); }
-                catch (const std::exception& e) { h->queues[k].err = e.what(); rcs[k] = VIT_ERR_NOMEM; }
-            });
+            workers.t.emplace_back([&, k] { rcs[k] = run_queue(h->queues[k], job, parts[k], &pack_ns[k]); });
         workers.join();
     }
-    host_workers.join();
+    h->pool->wait(host_work);
+    host_work.reset();
     h->last_pack_ns = 0;
     for (uint64_t p : pack_ns) h->last_pack_ns = std::max(h->last_pack_ns, p);
     h->last_total_ns = ns_since(t0);
@@ -633,11 +869,17 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
                          double(h->last_total_ns) * 1e-6, host_idx.size(), h->queues[k].trace_log.c_str());
     for (size_t k = 0; k < rcs.size(); ++k)
         if (rcs[k] != VIT_OK) return fail(h, rcs[k], "device queue %zu: %s", k, h->queues[k].err.c_str());
+    // Every chunk brought the status word back behind its digests: no extra
+    // synchronisation here unless a kernel did flag something.
     for (size_t k = 0; k < h->queues.size(); ++k) {
-        uint32_t st = 0;
-        int rc = vit_device_status(h, int(k), &st);
-        if (rc) return rc;
-        if (st) return fail(h, VIT_ERR_DEVICE_STATUS, "device queue %zu flagged status %u", k, st);
+        Queue& q = h->queues[k];
+        if (!q.status_seen) continue;
+        const uint32_t seen = q.status_seen;
+        q.status_seen = 0;
+        uint32_t word = 0;
+        HIP_TRY(h, hipSetDevice(q.device));
+        if (int rc = read_status_word(h, q, &word)) return rc;      // clears the device word
+        return fail(h, VIT_ERR_DEVICE_STATUS, "device queue %zu flagged status %u", k, seen | word);
     }
     return VIT_OK;
     VIT_NOEXCEPT_END(h)
@@ -669,6 +911,13 @@ int vit_shard_plan(const uint32_t* nblocks, uint64_t n, int n_queues, uint32_t* 
     VIT_NOEXCEPT_END(nullptr)
 }
 
+int vit_launch_shape(int kernel, uint64_t n, uint32_t* blocks, uint32_t* threads)
+{
+    if (!blocks || !threads || kernel < 0 || kernel > 5 || n > 0xFFFFFFFFull) return VIT_ERR_ARG;
+    vit::launch_shape(vit::KernelVariant(kernel), n, blocks, threads);
+    return VIT_OK;
+}
+
 int vit_arena_alloc(vit_hasher* h, uint64_t bytes, void** out)
 {
     if (!h || !out) return VIT_ERR_ARG;
@@ -685,6 +934,11 @@ int vit_arena_free(vit_hasher* h, void* arena)
     return VIT_OK;
 }
 
+// The caller's arena is the host side of the staging: pieces of it go to the
+// queue's two device arenas in turn, so the copy of piece k+1 runs beside the
+// kernel of piece k.  Pieces are runs of consecutive objects whose slots ascend
+// through the arena (what vit_arena_pack writes); an arena whose offsets are
+// not in ascending order goes over in one piece.
 int vit_hash_arena(vit_hasher* h, int dev, const void* arena, uint64_t arena_bytes, const uint64_t* offsets,
                    const uint32_t* nblocks, uint64_t n, uint8_t* digests)
 {
@@ -692,9 +946,10 @@ int vit_hash_arena(vit_hasher* h, int dev, const void* arena, uint64_t arena_byt
     if (!q) return h ? fail(h, VIT_ERR_ARG, "no device queue %d", dev) : VIT_ERR_ARG;
     if (n == 0) return VIT_OK;
     if (!arena || !offsets || !nblocks || !digests) return fail(h, VIT_ERR_ARG, "null argument");
-    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 objects in one call");
+    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 - 1 objects in one call");
     VIT_NOEXCEPT_BEGIN
-    uint64_t lo = ~0ull, hi = 0, blocks = 0;
+    bool ascending = true;
+    uint64_t blocks = 0;
     for (uint64_t i = 0; i < n; ++i) {
         const uint64_t sz = uint64_t(nblocks[i]) * 64;
         if (offsets[i] & 15) return fail(h, VIT_ERR_RANGE, "object %llu: offset not 16-byte aligned", (unsigned long long)i);
@@ -702,36 +957,62 @@ int vit_hash_arena(vit_hasher* h, int dev, const void* arena, uint64_t arena_byt
             return fail(h, VIT_ERR_RANGE, "object %llu: %llu blocks at offset %llu exceed the arena (%llu bytes)",
                         (unsigned long long)i, (unsigned long long)nblocks[i], (unsigned long long)offsets[i],
                         (unsigned long long)arena_bytes);
-        lo = std::min(lo, offsets[i]); hi = std::max(hi, offsets[i] + sz); blocks += nblocks[i];
+        if (i && offsets[i] < offsets[i - 1] + uint64_t(nblocks[i - 1]) * 64) ascending = false;
+        blocks += nblocks[i];
     }
-    lo &= ~uint64_t(63);
-    const uint64_t span = hi > lo ? hi - lo : 0;
+    drain(*q);
+    q->status_seen = 0;
     HIP_TRY(h, hipSetDevice(q->device));
-    Staging& s = q->st[0];
-    // Device-side staging only: the caller's arena is the host side.
-    if (span > s.d_cap) {
-        if (s.d_arena) { HIP_TRY(h, hipFree(s.d_arena)); s.d_arena = nullptr; s.d_cap = 0; }
-        if (s.h_arena) { HIP_TRY(h, hipHostFree(s.h_arena)); s.h_arena = nullptr; s.h_cap = 0; }
-        const uint64_t cap = round_up(span < (1ull << 20) ? (1ull << 20) : span, 1ull << 20);
-        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&s.d_arena), cap));
-        s.d_cap = cap;
+    const uint8_t* base = static_cast<const uint8_t*>(arena);
+
+    // [first, end) object ranges, each spanning at most `budget` bytes of the arena (one object at least)
+    std::vector<std::pair<uint64_t, uint64_t>> pieces;
+    if (!ascending) pieces.emplace_back(0, n);
+    else {
+        const uint64_t budget = std::max<uint64_t>(h->chunk_bytes, 1ull << 20);
+        for (uint64_t pos = 0; pos < n;) {
+            const uint64_t lo = offsets[pos] & ~uint64_t(63);
+            uint64_t end = pos + 1;
+            while (end < n && offsets[end] + uint64_t(nblocks[end]) * 64 - lo <= budget) ++end;
+            pieces.emplace_back(pos, end);
+            pos = end;
+        }
     }
-    if (int rc = ensure_meta(*q, s, n)) return fail(h, rc, "%s", q->err.c_str());
-    const uint64_t meta_bytes = carve_meta(s, n);
-    for (uint64_t i = 0; i < n; ++i) { s.h_off[i] = offsets[i] - lo; s.h_nb[i] = nblocks[i]; }
-    const bool binned = vit::bin_order(s.h_nb, n, s.h_order);
-    HIP_TRY(h, hipMemcpyAsync(s.d_arena, static_cast<const uint8_t*>(arena) + lo, span, hipMemcpyHostToDevice, q->stream[0]));
-    HIP_TRY(h, hipMemcpyAsync(s.d_meta, s.h_meta, meta_bytes + (binned ? meta_bytes / 3 : 0), hipMemcpyHostToDevice, q->stream[0]));
-    HIP_TRY(h, vit::launch_sha1(vit::KernelVariant(h->kernel),
-                                make_batch(*q, s.d_arena, span, s.d_off, s.d_nb, binned ? s.d_order : nullptr, n, s.d_dig),
-                                q->stream[0]));
-    HIP_TRY(h, hipMemcpyAsync(s.h_dig, s.d_dig, n * 20, hipMemcpyDeviceToHost, q->stream[0]));
-    HIP_TRY(h, hipStreamSynchronize(q->stream[0]));
-    std::memcpy(digests, s.h_dig, n * 20);
-    h->objects_gpu += n; h->blocks_gpu += blocks; h->bytes_h2d += span + n * 16; ++h->launches;
-    uint32_t st = 0;
-    if (int rc = vit_device_status(h, dev, &st)) return rc;
-    if (st) return fail(h, VIT_ERR_DEVICE_STATUS, "device queue %d flagged status %u", dev, st);
+    int rc = VIT_OK;
+    int turn = 0;
+    for (const auto& pc : pieces) {
+        Staging& s = q->st[turn];
+        hipStream_t stream = q->stream[turn];
+        turn ^= 1;
+        if ((rc = retire(*q, s, digests))) break;
+        const uint64_t cnt = pc.second - pc.first;
+        uint64_t lo = ~0ull, hi = 0;
+        for (uint64_t i = pc.first; i < pc.second; ++i) {
+            lo = std::min(lo, offsets[i]);
+            hi = std::max(hi, offsets[i] + uint64_t(nblocks[i]) * 64);
+        }
+        lo &= ~uint64_t(63);
+        const uint64_t span = hi > lo ? hi - lo : 0;
+        if ((rc = ensure_device_arena(*q, s, std::max<uint64_t>(span, 64)))) break;
+        if ((rc = ensure_meta(*q, s, cnt))) break;
+        const uint64_t meta_bytes = carve_meta(s, cnt);
+        for (uint64_t i = 0; i < cnt; ++i) { s.h_off[i] = offsets[pc.first + i] - lo; s.h_nb[i] = nblocks[pc.first + i]; }
+        const bool binned = vit::bin_order(s.h_nb, cnt, s.h_order);
+        s.obj.clear(); s.first = pc.first; s.count = cnt; s.traced = false;
+        if ((rc = launch_chunk(*q, h, s, stream, base + lo, span, meta_bytes, binned, cnt, false))) break;
+        h->bytes_h2d += span + cnt * 16; ++h->launches;
+    }
+    for (Staging& s : q->st)
+        if (rc == VIT_OK) rc = retire(*q, s, digests);
+    if (rc != VIT_OK) { drain(*q); return fail(h, rc, "device queue %d: %s", dev, q->err.c_str()); }
+    h->objects_gpu += n; h->blocks_gpu += blocks;
+    if (q->status_seen) {
+        const uint32_t seen = q->status_seen;
+        q->status_seen = 0;
+        uint32_t word = 0;
+        if (int rc2 = read_status_word(h, *q, &word)) return rc2;
+        return fail(h, VIT_ERR_DEVICE_STATUS, "device queue %d flagged status %u", dev, seen | word);
+    }
     return VIT_OK;
     VIT_NOEXCEPT_END(h)
 }
@@ -743,7 +1024,7 @@ int vit_hash_arena_device(vit_hasher* h, int dev, const void* d_arena, uint64_t 
     if (!q) return h ? fail(h, VIT_ERR_ARG, "no device queue %d", dev) : VIT_ERR_ARG;
     if (n == 0) return VIT_OK;
     if (!d_arena || !d_offsets || !d_nblocks || !d_digests) return fail(h, VIT_ERR_ARG, "null argument");
-    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 objects in one call");
+    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 - 1 objects in one call");
     if (reinterpret_cast<uintptr_t>(d_arena) & 15) return fail(h, VIT_ERR_RANGE, "arena not 16-byte aligned");
     HIP_TRY(h, hipSetDevice(q->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : q->stream[0];
@@ -759,7 +1040,7 @@ int vit_bin_order_device(vit_hasher* h, int dev, const uint32_t* d_nblocks, uint
     if (!q) return h ? fail(h, VIT_ERR_ARG, "no device queue %d", dev) : VIT_ERR_ARG;
     if (n == 0) return VIT_OK;
     if (!d_nblocks || !d_order) return fail(h, VIT_ERR_ARG, "null argument");
-    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 objects in one call");
+    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 - 1 objects in one call");
     HIP_TRY(h, hipSetDevice(q->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : q->stream[0];
     const size_t need = vit::bin_order_scratch_bytes(uint32_t(n));
@@ -773,14 +1054,19 @@ int vit_bin_order_device(vit_hasher* h, int dev, const uint32_t* d_nblocks, uint
     return VIT_OK;
 }
 
+// Waits for the queue's own three streams only (a launch the caller put on a
+// stream of its own is the caller's to wait for), then reads the word with an
+// asynchronous copy on one of them: no other stream of the device is stalled.
 int vit_device_status(vit_hasher* h, int dev, uint32_t* status)
 {
     Queue* q = queue_of(h, dev);
     if (!q || !status) return h ? fail(h, VIT_ERR_ARG, "bad arguments") : VIT_ERR_ARG;
     HIP_TRY(h, hipSetDevice(q->device));
-    HIP_TRY(h, hipDeviceSynchronize());
-    HIP_TRY(h, hipMemcpy(status, q->d_status, 4, hipMemcpyDeviceToHost));
-    if (*status) HIP_TRY(h, hipMemset(q->d_status, 0, 4));
+    for (hipStream_t st : q->stream) HIP_TRY(h, hipStreamSynchronize(st));
+    uint32_t word = 0;
+    if (int rc = read_status_word(h, *q, &word)) return rc;
+    *status = word | q->status_seen;
+    q->status_seen = 0;
     return VIT_OK;
 }
 
@@ -841,7 +1127,7 @@ int vit_synth_arena_device(vit_hasher* h, int dev, const char* type, uint64_t se
     if (!tl) return fail(h, VIT_ERR_ARG, "bad object type");
     if (n == 0) return VIT_OK;
     if (!d_offsets || !d_nblocks || !d_arena) return fail(h, VIT_ERR_ARG, "null argument");
-    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 objects in one call");
+    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 - 1 objects in one call");
     if (!d_lens) {
         const uint64_t need = vit_object_blocks(type, len_each) * 64 * n;
         if (need > arena_bytes) return fail(h, VIT_ERR_RANGE, "arena holds %llu bytes, %llu needed",

@@ -7,33 +7,43 @@
 
 namespace vit {
 
+// Cut [0, n) into `parts` contiguous ranges of balanced weight (weight_prefix:
+// n + 1 non-decreasing entries, or nullptr for equal weights).  Returns
+// parts + 1 boundaries; a range may be empty.
+inline std::vector<uint64_t> balanced_cuts(uint64_t n, int parts, const uint64_t* weight_prefix)
+{
+    if (parts < 1) parts = 1;
+    std::vector<uint64_t> cut(size_t(parts) + 1, 0);
+    cut[size_t(parts)] = n;
+    const uint64_t total = weight_prefix ? weight_prefix[n] - weight_prefix[0] : n;
+    for (int t = 1; t < parts; ++t) {
+        if (weight_prefix) {
+            const uint64_t target = weight_prefix[0] + total * uint64_t(t) / uint64_t(parts);
+            cut[size_t(t)] = uint64_t(std::lower_bound(weight_prefix, weight_prefix + n + 1, target) - weight_prefix);
+            if (cut[size_t(t)] > n) cut[size_t(t)] = n;
+        } else {
+            cut[size_t(t)] = n * uint64_t(t) / uint64_t(parts);
+        }
+        if (cut[size_t(t)] < cut[size_t(t) - 1]) cut[size_t(t)] = cut[size_t(t) - 1];
+    }
+    return cut;
+}
+
 // Run fn(t, begin, end) over [0, n) split into `threads` contiguous ranges whose
-// weights (weight_prefix, n + 1 entries, non-decreasing) are balanced.  With one
-// thread, or little work, runs inline.
+// weights are balanced, on threads started for the call.  With one thread, or
+// little work, runs inline.
 template <typename Fn>
 void parallel_ranges(uint64_t n, int threads, const uint64_t* weight_prefix, Fn fn)
 {
     if (n == 0) return;
     if (threads <= 1 || n < 2) { fn(0, uint64_t(0), n); return; }
     if (uint64_t(threads) > n) threads = int(n);
-    std::vector<uint64_t> cut(size_t(threads) + 1, 0);
-    cut[size_t(threads)] = n;
-    const uint64_t total = weight_prefix ? weight_prefix[n] - weight_prefix[0] : n;
-    for (int t = 1; t < threads; ++t) {
-        if (weight_prefix) {
-            const uint64_t target = weight_prefix[0] + total * uint64_t(t) / uint64_t(threads);
-            cut[size_t(t)] = uint64_t(std::lower_bound(weight_prefix, weight_prefix + n + 1, target) - weight_prefix);
-            if (cut[size_t(t)] > n) cut[size_t(t)] = n;
-        } else {
-            cut[size_t(t)] = n * uint64_t(t) / uint64_t(threads);
-        }
-        if (cut[size_t(t)] < cut[size_t(t) - 1]) cut[size_t(t)] = cut[size_t(t) - 1];
-    }
+    const std::vector<uint64_t> cut = balanced_cuts(n, threads, weight_prefix);
     std::vector<std::thread> pool;
     pool.reserve(size_t(threads));
     for (int t = 0; t < threads; ++t) {
         if (cut[size_t(t)] == cut[size_t(t) + 1]) continue;
-        pool.emplace_back([=, &fn] { fn(t, cut[size_t(t)], cut[size_t(t) + 1]); });
+        pool.emplace_back([=, &fn, &cut] { fn(t, cut[size_t(t)], cut[size_t(t) + 1]); });
     }
     for (auto& th : pool) th.join();
 }

@@ -37,6 +37,8 @@ enum : uint32_t {
 };
 
 hipError_t launch_sha1(KernelVariant v, const DeviceBatch& b, hipStream_t stream);
+// Launch shape for n objects (n up to 2^32 - 1): workgroups, threads per workgroup.
+void launch_shape(KernelVariant v, uint64_t n, uint32_t* blocks, uint32_t* threads);
 
 // Synthetic framed arena, generated on the device (benchmark and full-size
 // parity inputs; the reference has no benchmark data of its own).

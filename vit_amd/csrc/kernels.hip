@@ -348,22 +348,35 @@ __global__ __launch_bounds__(256) void sha1_lane_kernel(DeviceBatch b)
     store_digest(b.digests, idx, h);
 }
 
+// Workgroups and threads per workgroup of a launch over n objects.  64-bit
+// arithmetic: n may be anything up to 2^32 - 1, and n + 255 must not wrap.
+void launch_shape(KernelVariant v, uint64_t n, uint32_t* blocks, uint32_t* threads)
+{
+    uint64_t wpb;                       // waves per workgroup
+    switch (int(v)) {
+    case KERNEL_LANE: wpb = 4; break;
+    case 2: case 3: case 5: wpb = 1; break;
+    case 4: wpb = 2; break;
+    default: wpb = 4; break;
+    }
+    const uint64_t waves = (n + 63u) / 64u;
+    *blocks = uint32_t((waves + wpb - 1) / wpb);
+    *threads = uint32_t(64u * wpb);
+}
+
 hipError_t launch_sha1(KernelVariant v, const DeviceBatch& b, hipStream_t stream)
 {
     if (b.n == 0) return hipSuccess;
-    if (v == KERNEL_LANE) {
-        const uint32_t grid = (b.n + 255u) / 256u;
-        hipLaunchKernelGGL(sha1_lane_kernel, dim3(grid), dim3(256), 0, stream, b);
-    } else {
-        const uint32_t waves = (b.n + 63u) / 64u;
-        auto grid = [&](uint32_t wpb) { return dim3((waves + wpb - 1) / wpb); };
-        switch (int(v)) {      // 2..5: other stage depths / workgroup shapes, kept for A/B measurement
-        case 2:  hipLaunchKernelGGL((sha1_lds_kernel<1, 1>), grid(1), dim3(64), 0, stream, b); break;
-        case 3:  hipLaunchKernelGGL((sha1_lds_kernel<4, 1>), grid(1), dim3(64), 0, stream, b); break;
-        case 4:  hipLaunchKernelGGL((sha1_lds_kernel<2, 2>), grid(2), dim3(128), 0, stream, b); break;
-        case 5:  hipLaunchKernelGGL((sha1_lds_kernel<2, 1>), grid(1), dim3(64), 0, stream, b); break;
-        default: hipLaunchKernelGGL((sha1_lds_kernel<2, 4>), grid(4), dim3(256), 0, stream, b); break;
-        }
+    uint32_t blocks = 0, threads = 0;
+    launch_shape(v, b.n, &blocks, &threads);
+    const dim3 grid(blocks), block(threads);
+    switch (int(v)) {          // 2..5: other stage depths / workgroup shapes, kept for A/B measurement
+    case KERNEL_LANE: hipLaunchKernelGGL(sha1_lane_kernel, grid, block, 0, stream, b); break;
+    case 2:  hipLaunchKernelGGL((sha1_lds_kernel<1, 1>), grid, block, 0, stream, b); break;
+    case 3:  hipLaunchKernelGGL((sha1_lds_kernel<4, 1>), grid, block, 0, stream, b); break;
+    case 4:  hipLaunchKernelGGL((sha1_lds_kernel<2, 2>), grid, block, 0, stream, b); break;
+    case 5:  hipLaunchKernelGGL((sha1_lds_kernel<2, 1>), grid, block, 0, stream, b); break;
+    default: hipLaunchKernelGGL((sha1_lds_kernel<2, 4>), grid, block, 0, stream, b); break;
     }
     return hipGetLastError();
 }

@@ -1,0 +1,139 @@
+// work_pool.h — the hasher's ONE set of host worker threads.
+//
+// Everything on the host side of a batch that is worth a thread runs here:
+// packing staging chunks for every device queue, and the SHA-1 streams of the
+// objects kept off the GPU.  One pool per hasher, sized to the cores once
+// (option "pack_threads"), shared by all device queues: the number of live
+// worker threads does not grow with the number of GPUs.
+//
+// Work comes as GROUPS of n indexed tasks with one of two priorities.  Workers
+// always serve the oldest high-priority group first (chunk packing: short tasks
+// that keep a copy engine fed), then the oldest low-priority group (host-lane
+// objects: long tasks nobody waits on until the end of the batch).  The thread
+// that waits for a group helps with that group's tasks, so a group completes
+// even on a pool of zero threads and a waiting device-queue thread is not idle.
+#pragma once
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace vit {
+
+class WorkPool {
+public:
+    enum Priority { HIGH = 0, LOW = 1 };
+
+    struct Group {
+        std::function<void(size_t)> fn;
+        size_t n = 0;
+        size_t next = 0;                 // next unclaimed task (guarded by the pool's mutex)
+        size_t done = 0;                 // finished tasks (guarded by the pool's mutex)
+        std::condition_variable finished;
+    };
+    using Ticket = std::shared_ptr<Group>;
+
+    explicit WorkPool(int threads) { resize(threads); }
+    ~WorkPool() { stop(); }
+    WorkPool(const WorkPool&) = delete;
+    WorkPool& operator=(const WorkPool&) = delete;
+
+    int threads() const { return int(workers_.size()); }
+
+    // Most worker threads that were inside a task at the same moment since the
+    // last reset (the calling threads that help are not counted).
+    int peak_busy() const { return peak_busy_.load(); }
+    void reset_peak() { peak_busy_ = 0; }
+
+    // Stop the workers and start `threads` new ones.  Only between batches.
+    void resize(int threads)
+    {
+        stop();
+        stop_ = false;
+        for (int i = 0; i < threads; ++i) workers_.emplace_back([this] { work(); });
+    }
+
+    // Queue fn(0) .. fn(n-1); returns at once.  fn must not throw.
+    Ticket submit(Priority prio, size_t n, std::function<void(size_t)> fn)
+    {
+        Ticket g = std::make_shared<Group>();
+        g->fn = std::move(fn);
+        g->n = n;
+        if (n == 0) return g;
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            open_[prio].push_back(g);
+        }
+        if (n == 1) wake_.notify_one(); else wake_.notify_all();
+        return g;
+    }
+
+    // Help with the group's unclaimed tasks, then wait for the claimed ones.
+    void wait(const Ticket& g)
+    {
+        if (!g || g->n == 0) return;
+        std::unique_lock<std::mutex> lk(m_);
+        while (g->next < g->n) {
+            const size_t i = g->next++;
+            if (g->next == g->n) drop(g);
+            lk.unlock();
+            g->fn(i);
+            lk.lock();
+            ++g->done;
+        }
+        g->finished.wait(lk, [&] { return g->done == g->n; });
+    }
+
+    // submit + wait.
+    void run(Priority prio, size_t n, std::function<void(size_t)> fn) { wait(submit(prio, n, std::move(fn))); }
+
+private:
+    void drop(const Ticket& g)           // with m_ held: the group has no unclaimed task left
+    {
+        for (auto& q : open_)
+            for (auto it = q.begin(); it != q.end(); ++it)
+                if (*it == g) { q.erase(it); return; }
+    }
+
+    void work()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            wake_.wait(lk, [this] { return stop_ || !open_[HIGH].empty() || !open_[LOW].empty(); });
+            if (stop_) return;
+            Ticket g = !open_[HIGH].empty() ? open_[HIGH].front() : open_[LOW].front();
+            const size_t i = g->next++;
+            if (g->next == g->n) drop(g);
+            const int busy = ++busy_;
+            int peak = peak_busy_.load();
+            while (busy > peak && !peak_busy_.compare_exchange_weak(peak, busy)) {}
+            lk.unlock();
+            g->fn(i);
+            lk.lock();
+            --busy_;
+            if (++g->done == g->n) g->finished.notify_all();
+        }
+    }
+
+    void stop()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        wake_.notify_all();
+        for (auto& w : workers_) if (w.joinable()) w.join();
+        workers_.clear();
+    }
+
+    std::vector<std::thread> workers_;
+    std::deque<Ticket> open_[2];
+    std::mutex m_;
+    std::condition_variable wake_;
+    bool stop_ = false;
+    int busy_ = 0;
+    std::atomic<int> peak_busy_{0};
+};
+
+}  // namespace vit
