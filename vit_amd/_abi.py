@@ -44,6 +44,7 @@ SIGNATURES = {
     "vit_launch_shape": (C.c_int, [C.c_int, C.c_uint64, u32p, u32p]),
     "vit_hash_arena": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp, C.c_uint64, vp]),
     "vit_hash_arena_device": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp]),
+    "vit_hash_arena_device_static": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp]),
     "vit_device_status": (C.c_int, [vp, C.c_int, u32p]),
     "vit_device_alloc": (C.c_int, [vp, C.c_int, C.c_uint64, C.POINTER(vp)]),
     "vit_device_free": (C.c_int, [vp, C.c_int, vp]),

@@ -69,6 +69,8 @@ struct Queue {
     uint32_t* d_status = nullptr;                          // device: word 0 = STATUS_* bits; bytes 1024.. = calibration output
     uint32_t* h_status = nullptr;                          // pinned: where vit_device_status reads that word to
     uint32_t  status_seen = 0;                             // bits the chunks of host-memory calls have brought back
+    void*     scratch = nullptr;                           // this DEVICE's address of the kernels' file-scope scratch array
+                                                           // (vit_hash_arena_device_static); shared by every queue on the device
     uint64_t  chunks_this_call = 0;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     void* sort_scratch = nullptr; size_t sort_scratch_bytes = 0;   // vit_bin_order_device
@@ -498,14 +500,17 @@ void shard(const std::vector<uint64_t>& idx, const uint32_t* nb, size_t nq, std:
     for (auto& v : out) std::sort(v.begin(), v.end());
 }
 
-// Read the queue's device status word through its first stream and clear it if set.
+// Read the queue's device status word, and the one in the device's static
+// scratch, through the queue's first stream; clear what was set.
 int read_status_word(vit_hasher* h, Queue& q, uint32_t* out)
 {
-    HIP_TRY(h, hipMemcpyAsync(q.h_status, q.d_status, 4, hipMemcpyDeviceToHost, q.stream[0]));
+    HIP_TRY(h, hipMemcpyAsync(&q.h_status[0], q.d_status, 4, hipMemcpyDeviceToHost, q.stream[0]));
+    HIP_TRY(h, hipMemcpyAsync(&q.h_status[1], q.scratch, 4, hipMemcpyDeviceToHost, q.stream[0]));
     HIP_TRY(h, hipStreamSynchronize(q.stream[0]));
-    *out = *q.h_status;
+    *out = q.h_status[0] | q.h_status[1];
     if (*out) {
-        HIP_TRY(h, hipMemsetAsync(q.d_status, 0, 4, q.stream[0]));
+        if (q.h_status[0]) HIP_TRY(h, hipMemsetAsync(q.d_status, 0, 4, q.stream[0]));
+        if (q.h_status[1]) HIP_TRY(h, hipMemsetAsync(q.scratch, 0, 4, q.stream[0]));
         HIP_TRY(h, hipStreamSynchronize(q.stream[0]));
     }
     return VIT_OK;
@@ -632,6 +637,11 @@ int vit_hasher_create(const int* device_ids, int n_devices, vit_hasher** out)
         // The kernels run on non-blocking streams, which the null stream does not
         // order with: clear the word on the stream that will use it, and wait.
         if (r == hipSuccess) r = hipMemsetAsync(q.d_status, 0, kStatusBytes, q.stream[0]);
+        if (r == hipSuccess) r = hipStreamSynchronize(q.stream[0]);
+        // The file-scope scratch array has one copy per GPU: ask for this device's
+        // address now, with the device current, and clear its status word.
+        if (r == hipSuccess) r = vit::static_scratch_address(&q.scratch);
+        if (r == hipSuccess) r = hipMemsetAsync(q.scratch, 0, 256, q.stream[0]);
         if (r == hipSuccess) r = hipStreamSynchronize(q.stream[0]);
         if (r == hipSuccess) r = hipEventCreate(&q.ev_a);
         if (r == hipSuccess) r = hipEventCreate(&q.ev_b);
@@ -1030,6 +1040,30 @@ int vit_hash_arena_device(vit_hasher* h, int dev, const void* d_arena, uint64_t 
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : q->stream[0];
     HIP_TRY(h, vit::launch_sha1(vit::KernelVariant(h->kernel),
                                 make_batch(*q, d_arena, arena_bytes, d_offsets, d_nblocks, d_order, n, d_digests), s));
+    ++h->launches; h->objects_gpu += n;
+    return VIT_OK;
+}
+
+// Allocates nothing: the order array, the binning counters and the status word
+// live in the kernels' file-scope device array, whose address on this queue's
+// device was taken at vit_hasher_create.
+int vit_hash_arena_device_static(vit_hasher* h, int dev, const void* d_arena, uint64_t arena_bytes,
+                                 const uint64_t* d_offsets, const uint32_t* d_nblocks, uint64_t n, uint8_t* d_digests,
+                                 void* stream)
+{
+    Queue* q = queue_of(h, dev);
+    if (!q) return h ? fail(h, VIT_ERR_ARG, "no device queue %d", dev) : VIT_ERR_ARG;
+    if (n == 0) return VIT_OK;
+    if (!d_arena || !d_offsets || !d_nblocks || !d_digests) return fail(h, VIT_ERR_ARG, "null argument");
+    if (n > vit::STATIC_MAX_OBJECTS)
+        return fail(h, VIT_ERR_RANGE, "%llu objects: the entry point that allocates nothing takes at most %u per call",
+                    (unsigned long long)n, vit::STATIC_MAX_OBJECTS);
+    if (reinterpret_cast<uintptr_t>(d_arena) & 15) return fail(h, VIT_ERR_RANGE, "arena not 16-byte aligned");
+    HIP_TRY(h, hipSetDevice(q->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : q->stream[0];
+    HIP_TRY(h, vit::launch_sha1_static(vit::KernelVariant(h->kernel),
+                                       make_batch(*q, d_arena, arena_bytes, d_offsets, d_nblocks, nullptr, n, d_digests),
+                                       q->scratch, s));
     ++h->launches; h->objects_gpu += n;
     return VIT_OK;
 }

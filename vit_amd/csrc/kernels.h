@@ -67,6 +67,15 @@ size_t bin_order_scratch_bytes(uint32_t n);
 hipError_t bin_order_device(const uint32_t* d_nblocks, uint32_t n, uint32_t* d_order, void* scratch,
                             size_t scratch_bytes, hipStream_t stream);
 
+// The launch of the entry point that allocates nothing: length-bins the batch on the device into a
+// file-scope device array (about 8 MiB per GPU, held for the life of the process), then hashes in that
+// order; status bits go to a word in the same array.  b.order and b.status are ignored.  scratch_ptr is
+// what static_scratch_address() returned ON THE DEVICE THE LAUNCH GOES TO.
+constexpr uint32_t STATIC_MAX_OBJECTS = 1u << 21;
+hipError_t static_scratch_address(void** out);        // hipGetSymbolAddress for the current device
+uint64_t static_scratch_bytes();
+hipError_t launch_sha1_static(KernelVariant v, DeviceBatch b, void* scratch_ptr, hipStream_t stream);
+
 // Compute-only ceiling: every lane runs `blocks_per_lane` SHA-1 compressions on
 // register-resident data (no loads in the loop).  out: one dword per lane.
 hipError_t launch_valu_peak(uint32_t* out, uint32_t n_lanes, uint32_t blocks_per_lane,

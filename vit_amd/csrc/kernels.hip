@@ -496,6 +496,135 @@ hipError_t bin_order_device(const uint32_t* d_nblocks, uint32_t n, uint32_t* d_o
     return rocprim::radix_sort_pairs_desc(temp, temp_bytes, d_nblocks, keys_out, iota, d_order, n, 0, 32, stream);
 }
 
+// ------------------------------------------- binning into static scratch --
+// Length binning without any allocation, for the entry point that may not
+// allocate: a counting sort of the objects by a monotone bucket of their block
+// count, longest bucket first, into a file-scope device array.
+//
+//   bucket(nb) = nb                                    for nb < 256
+//              = 256 + 16*(log2(nb) - 8) + next 4 bits  above (16 buckets per octave)
+//
+// so short objects are binned exactly and long ones to within 1/16 of their
+// length, which is all the wave needs (its lanes finish within ~6 % of each
+// other).  Three launches: histogram (LDS-privatised per workgroup), one
+// workgroup turning the histogram into start positions in descending bucket
+// order, and a scatter in which every workgroup reserves one range per bucket
+// (an LDS counter ranks its own objects; one global atomic per workgroup and
+// bucket), so a workgroup's objects of one bucket stay together and in a batch
+// of equal lengths a wave still reads neighbouring slots.
+constexpr uint32_t kBins = 640;                     // 256 + 16 * (32 - 8)
+constexpr uint32_t kBinItems = 4;                   // objects per thread in the histogram / scatter kernels
+constexpr uint64_t kScratchStatus  = 0;             // u32 status word (STATUS_* bits)
+constexpr uint64_t kScratchHist    = 256;           // u32[kBins]  histogram
+constexpr uint64_t kScratchCursor  = 256 + 4096;    // u32[kBins]  next free position per bucket
+constexpr uint64_t kScratchOrder   = 256 + 8192;    // u32[STATIC_MAX_OBJECTS]
+constexpr uint64_t kScratchBytes   = kScratchOrder + 4ull * STATIC_MAX_OBJECTS;
+static_assert(kBins * 4 <= 4096, "histogram and cursor regions are 4 KiB each");
+
+// The scratch of vit_hash_arena_device_static.  Each GPU holds its own copy of
+// this array at its own address; host code never uses the NAME below as an
+// address (it is only a host-side handle): static_scratch_address() asks the
+// runtime for the current device's address, once per device, and everything
+// else — kernel arguments, memsets, copies — uses that pointer.
+static __device__ __align__(256) uint8_t scratch[kScratchBytes];
+
+hipError_t static_scratch_address(void** out)
+{
+    return hipGetSymbolAddress(out, HIP_SYMBOL(scratch));
+}
+
+uint64_t static_scratch_bytes() { return kScratchBytes; }
+
+__device__ __forceinline__ uint32_t bin_of(uint32_t nb)
+{
+    if (nb < 256u) return nb;
+    const uint32_t lg = 31u - (uint32_t)__clz((int)nb);            // 8..31
+    return 256u + 16u * (lg - 8u) + ((nb >> (lg - 4u)) & 15u);
+}
+
+__global__ __launch_bounds__(256) void bin_hist_kernel(const uint32_t* nblocks, uint32_t n, uint32_t* hist)
+{
+    __shared__ uint32_t local[kBins];
+    for (uint32_t b = threadIdx.x; b < kBins; b += 256u) local[b] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (256u * kBinItems);
+#pragma unroll
+    for (uint32_t k = 0; k < kBinItems; ++k) {
+        const uint32_t i = base + k * 256u + threadIdx.x;
+        if (i < n) atomicAdd(&local[bin_of(nblocks[i])], 1u);
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < kBins; b += 256u)
+        if (local[b]) atomicAdd(&hist[b], local[b]);
+}
+
+// One workgroup of kBins threads: cursor[b] = number of objects in buckets above b.
+__global__ __launch_bounds__(kBins) void bin_start_kernel(const uint32_t* hist, uint32_t* cursor)
+{
+    __shared__ uint32_t part[kBins];
+    const uint32_t t = threadIdx.x;                 // thread t looks at bucket kBins-1-t: descending order
+    part[t] = hist[kBins - 1u - t];
+    __syncthreads();
+    for (uint32_t step = 1; step < kBins; step <<= 1) {            // inclusive scan, Hillis-Steele
+        const uint32_t add = t >= step ? part[t - step] : 0u;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    cursor[kBins - 1u - t] = part[t] - hist[kBins - 1u - t];       // exclusive
+}
+
+__global__ __launch_bounds__(256) void bin_scatter_kernel(const uint32_t* nblocks, uint32_t n, uint32_t* cursor,
+                                                          uint32_t* order)
+{
+    __shared__ uint32_t count[kBins];
+    __shared__ uint32_t start[kBins];
+    for (uint32_t b = threadIdx.x; b < kBins; b += 256u) count[b] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (256u * kBinItems);
+    uint32_t bin[kBinItems], rank[kBinItems];
+#pragma unroll
+    for (uint32_t k = 0; k < kBinItems; ++k) {
+        const uint32_t i = base + k * 256u + threadIdx.x;
+        bin[k] = rank[k] = 0;
+        if (i < n) { bin[k] = bin_of(nblocks[i]); rank[k] = atomicAdd(&count[bin[k]], 1u); }
+    }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < kBins; b += 256u)
+        if (count[b]) start[b] = atomicAdd(&cursor[b], count[b]);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kBinItems; ++k) {
+        const uint32_t i = base + k * 256u + threadIdx.x;
+        if (i < n) {
+            const uint32_t pos = start[bin[k]] + rank[k];
+            if (pos < n) order[pos] = i;            // always true; keeps a corrupted count from writing past the array
+        }
+    }
+}
+
+hipError_t launch_sha1_static(KernelVariant v, DeviceBatch b, void* scratch_ptr, hipStream_t stream)
+{
+    if (b.n == 0) return hipSuccess;
+    if (b.n > STATIC_MAX_OBJECTS || !scratch_ptr) return hipErrorInvalidValue;
+    uint8_t* s = static_cast<uint8_t*>(scratch_ptr);
+    uint32_t* hist = reinterpret_cast<uint32_t*>(s + kScratchHist);
+    uint32_t* cursor = reinterpret_cast<uint32_t*>(s + kScratchCursor);
+    uint32_t* order = reinterpret_cast<uint32_t*>(s + kScratchOrder);
+    // The array keeps the last call's contents: the histogram must start at zero
+    // (the cursors are overwritten, the order entries [0, n) all rewritten).
+    hipError_t e = hipMemsetAsync(hist, 0, kBins * 4, stream);
+    if (e != hipSuccess) return e;
+    const uint32_t groups = (b.n + 256u * kBinItems - 1u) / (256u * kBinItems);
+    hipLaunchKernelGGL(bin_hist_kernel, dim3(groups), dim3(256), 0, stream, b.nblocks, b.n, hist);
+    hipLaunchKernelGGL(bin_start_kernel, dim3(1), dim3(kBins), 0, stream, hist, cursor);
+    hipLaunchKernelGGL(bin_scatter_kernel, dim3(groups), dim3(256), 0, stream, b.nblocks, b.n, cursor, order);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    b.order = order;
+    b.status = reinterpret_cast<uint32_t*>(s + kScratchStatus);
+    return launch_sha1(v, b, stream);
+}
+
 // --------------------------------------------------------- compute ceiling --
 __global__ __launch_bounds__(256) void valu_peak_kernel(uint32_t* out, uint32_t n_lanes, uint32_t blocks)
 {

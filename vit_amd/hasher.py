@@ -260,6 +260,14 @@ class Hasher:
         self.sync(batch["dev"])
         return batch["digests"].download(np.uint8, 20 * batch["n"]).reshape(-1, 20)
 
+    def hash_device_static(self, batch):
+        """The launch that allocates nothing (device-side binning into the library's static scratch)."""
+        self._check(self.lib.vit_hash_arena_device_static(
+            self.handle, batch["dev"], batch["arena"].ptr, batch["arena_bytes"], batch["offsets"].ptr,
+            batch["nblocks"].ptr, batch["n"], batch["digests"].ptr, None))
+        self.sync(batch["dev"])
+        return batch["digests"].download(np.uint8, 20 * batch["n"]).reshape(-1, 20)
+
     def time_hash_device(self, batch, order=None, warmup=1, iters=5):
         ms = (C.c_float * max(iters, 1))()
         self._check(self.lib.vit_time_hash_device(
