@@ -7,7 +7,18 @@ that batch = one launch of the SHA-1 kernel through the C ABI
 (vit_hash_arena_device).  N > 1: one process per GPU (torch.distributed.run),
 every rank hashes its own 1M blobs (weak scaling, no data-path collective — each
 digest depends on its own blob only); the only communication is the timing
-barrier and the max-over-ranks of the elapsed time.
+barrier and the max-over-ranks of the elapsed time.  `value` is that and
+nothing else.
+
+Reported beside it, measured AFTER the timed region (rank 0; the other ranks
+wait on a CPU barrier, their GPUs idle):
+  end_to_end_host_memory   pack + H2D + kernel + D2H inside vit_hash_blobs, from host memory:
+      uniform_4k           the same 4 KiB blobs through one device queue
+      mixed_slice          a slice of BASELINE configs[3] (lognormal sizes up to 32 MiB) through ONE
+                           hasher over all N GPUs of the run (vit_hasher_create(ids, N)): the sharded
+                           host path, strong scaling (the slice is the same whatever N)
+  cpu_baseline             (N = 1) the reference's hashing loop and its whole write-tree, restated on
+                           the host's cores, on bounded samples
 
 Prints ONE JSON line on rank 0.
 """
@@ -27,32 +38,133 @@ SEED = 0x5EED0002           # config 2 of the synthetic-input plan
 N_BLOBS = 1_000_000
 BLOB_LEN = 4096
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E peak (spec)
-VALU_PEAK_TOPS = 39.3216    # 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: issue rate of the 3-input / shift integer ops
+# 256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz.  16 lanes per clock and SIMD is the issue rate this chip measured
+# (tools/valu_ubench.hip, profiles/r02_valu_ubench.txt) for every instruction with three register sources and for
+# shifts/rotates, i.e. for 533 of the 597 instructions of a SHA-1 block; two-source adds and xors issue at about
+# twice that alone, but not when mixed with the others.
+VALU_PEAK_TOPS = 39.3216
 OPS_PER_BLOCK = 597          # vector ops per 64-byte block: schedule 192 + rounds 400 + 5 chaining adds
+PCIE_GBS = 63.0              # PCIe Gen5 x16, per GPU and direction (spec; about 55 usable)
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--blobs", type=int, default=N_BLOBS, help="blobs per GPU (default: the BASELINE config)")
     ap.add_argument("--blob-len", type=int, default=BLOB_LEN)
     ap.add_argument("--kernel", choices=["lds", "lane"], default="lds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget for the baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work budget for the hash-loop baseline")
     ap.add_argument("--dist-backend", default=None,
                     help="torch.distributed backend for the timing barrier (default: nccl = RCCL; gloo lets two "
                          "ranks rehearse on one GPU)")
-    ap.add_argument("--end-to-end", action="store_true",
-                    help="also time pack + H2D + kernel + D2H from host memory (reported beside value, never as value); "
-                         "off by default so that a profile of the default command holds same-size launches only")
+    ap.add_argument("--no-end-to-end", action="store_true",
+                    help="skip the host-memory legs (a profile of that command then holds same-size launches only)")
+    ap.add_argument("--e2e-objects", type=int, default=500_000,
+                    help="objects in the mixed-size host-memory slice (15 KB mean: 500,000 = 7.5 GB)")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------ end to end --
+def mixed_sizes(n, seed=0x5EED0004, clip=32 << 20):
+    """BASELINE configs[3]'s size distribution: lognormal, median 4.5 KB, sigma 1.55, 15 KB mean, clipped."""
+    rng = np.random.default_rng(seed)
+    sizes = np.exp(rng.normal(np.log(4500.0), 1.55, n))
+    return np.minimum(sizes * (15000.0 / sizes.mean()), clip).astype(np.uint64)
+
+
+def fill_host(lib, seed, sizes, threads=16):
+    """One contiguous host buffer holding object i = synthetic stream (seed, i); returns (buf, offsets)."""
+    from concurrent.futures import ThreadPoolExecutor
+    n = len(sizes)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(sizes, out=offs[1:])
+    buf = np.empty(int(offs[-1]) + 1, dtype=np.uint8)
+    base = buf.ctypes.data
+
+    def part(r):
+        for i in range(r[0], r[1]):
+            lib.vit_synth_bytes(seed, i, base + int(offs[i]), int(sizes[i]))
+    step = max(1, (n + 8 * threads - 1) // (8 * threads))
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(part, [(i, min(i + step, n)) for i in range(0, n, step)]))
+    return buf, offs
+
+
+def time_host_batch(h, ptrs, sizes, n, runs=3):
+    """vit_hash_blobs on (ptrs, sizes): one untimed call sizes the staging buffers, then the median of `runs`."""
+    dig = np.zeros((n, 20), dtype=np.uint8)
+    call = lambda: h._check(h.lib.vit_hash_blobs(h.handle, ptrs.ctypes.data, sizes.ctypes.data, n, dig.ctypes.data))
+    call()
+    rec = []
+    for _ in range(runs):
+        g0, h0, b0, t0 = h.stat("objects_gpu"), h.stat("objects_host"), h.stat("bytes_host"), h.stat("bytes_h2d")
+        call()
+        rec.append((h.stat("last_total_ns"), h.stat("last_pack_ns"), h.stat("objects_gpu") - g0,
+                    h.stat("objects_host") - h0, h.stat("bytes_host") - b0, h.stat("bytes_h2d") - t0))
+    rec.sort()
+    return dig, rec[len(rec) // 2]
+
+
+def end_to_end(args, world, resident_digests):
+    import hashlib
+    import torch
+    import vit_amd
+    from vit_amd import _abi
+    lib = _abi.load()
+    out = {"note": "time inside vit_hash_blobs (pack + H2D + kernel + D2H); PCIe-bound, never reported as value",
+           "pcie_spec_GBps_per_gpu": PCIE_GBS}
+    n, L = min(args.blobs, 262144), args.blob_len
+    sizes = np.full(n, L, dtype=np.uint64)
+    buf, offs = fill_host(lib, SEED, sizes)
+    ptrs = (offs[:n] + np.uint64(buf.ctypes.data)).astype(np.uint64)
+    with vit_amd.Hasher((0,)) as h:
+        dig, (total_ns, pack_ns, _, _, _, h2d) = time_host_batch(h, ptrs, sizes, n)
+        out["uniform_4k"] = {"value": round(n * L / total_ns, 3), "unit": "GB/s", "blobs": n, "queues": 1,
+                             "total_ms": round(total_ns / 1e6, 2), "pack_ms": round(pack_ns / 1e6, 2),
+                             "bytes_h2d": h2d, "pack_threads": h.stat("pool_threads") + 1,
+                             "matches_resident_digests": bool((dig == resident_digests[:n]).all())}
+    del buf
+
+    m = args.e2e_objects
+    if m > 0:
+        visible = max(torch.cuda.device_count(), 1)
+        ids = tuple(i % visible for i in range(world))
+        sizes = mixed_sizes(m)
+        buf, offs = fill_host(lib, 0x5EED0004, sizes)
+        ptrs = (offs[:m] + np.uint64(buf.ctypes.data)).astype(np.uint64)
+        payload = int(offs[-1])
+        with vit_amd.Hasher(ids) as h:
+            dig, (total_ns, pack_ns, on_gpu, on_host, bytes_host, h2d) = time_host_batch(h, ptrs, sizes, m)
+            rates = {k: h.stat(k) for k in ("lane_rate", "core_rate", "copy_rate", "pack_rate")}
+            threads = h.stat("pool_threads") + (len(ids) if len(ids) > 1 else 1)
+        mv = memoryview(buf)
+        ok = True
+        for i in [0, m - 1, int(np.argmax(sizes))] + np.random.default_rng(3).integers(0, m, 200).tolist():
+            hh = hashlib.sha1(b"blob %d\0" % int(sizes[i]))
+            hh.update(mv[int(offs[i]):int(offs[i + 1])])
+            ok = ok and hh.digest() == dig[i].tobytes()
+        out["mixed_slice"] = {
+            "value": round(payload / total_ns, 3), "unit": "GB/s", "objects_per_s": round(m / (total_ns * 1e-9), 1),
+            "scaling": "strong", "queues": len(ids), "device_ids": list(ids), "objects": m, "payload_bytes": payload,
+            "total_ms": round(total_ns / 1e6, 2), "pack_ms": round(pack_ns / 1e6, 2),
+            "objects_gpu": on_gpu, "objects_host": on_host, "bytes_host": bytes_host, "bytes_h2d": h2d,
+            "host_threads": threads, "measured_rates_bytes_per_s": rates,
+            "bound": "GPU side: %d x PCIe (%.0f GB/s spec each) or the host's DRAM/packing threads, whichever is lower; "
+                     "host side: %d threads x the measured core rate; the two sides run concurrently and add up"
+                     % (len(ids), PCIE_GBS, threads),
+            "workload": "BASELINE configs[3] sizes (lognormal, 15 KB mean, <= 32 MiB), objects above the balance point "
+                        "hashed on host threads meanwhile",
+            "ids_checked_vs_hashlib": 203, "matches": bool(ok)}
+    return out
+
+
+# --------------------------------------------------------------- CPU baseline --
 def cpu_baseline(args, gpu_digests_of_sample):
-    """The reference's hashing loop (src/commit.cpp:90-94) on host cores, on a
-    bounded sample of the same blobs.  Checker/measurement only."""
+    """The reference's hashing loop (src/commit.cpp:90-94) and its whole write-tree (:139-173, :98-111) on
+    host cores, on bounded samples.  Checker/measurement only."""
     from oracle import pyoracle as O
     n_sample = min(args.blobs, 65536)
     cores = os.cpu_count() or 1
@@ -86,26 +198,53 @@ def cpu_baseline(args, gpu_digests_of_sample):
                       "objects_per_s": round(n_sample / secn, 1)},
         "gpu_matches_cpu_on_sample": parity,
     }
-    # The reference's full per-object path (hash + zlib + loose-object write), from its own commit.cpp.
-    ref = O.ref_lib()
-    if ref is not None:
-        import tempfile
-        cwd = os.getcwd()
-        with tempfile.TemporaryDirectory() as td:
-            os.makedirs(os.path.join(td, ".git", "objects"))
-            os.chdir(td)
-            try:
-                m = min(n_sample, 2000)
-                t0 = time.perf_counter()
-                for i in range(m):
-                    O.ref_write_blob(blobs[i * args.blob_len:(i + 1) * args.blob_len].tobytes())
-                dt = time.perf_counter() - t0
-            finally:
-                os.chdir(cwd)
-        out["reference_write_blob"] = {"objects_per_s": round(m / dt, 1), "value": round(m * args.blob_len / dt / 1e9, 5),
-                                       "unit": "GB/s", "cores": 1, "kind": "reference",
-                                       "sample": "%d blobs through the reference's writeBlob (SHA1 + zlib + file write)" % m}
+    out["write_tree"] = cpu_write_tree(O)
     return out
+
+
+def cpu_write_tree(O):
+    """Reference-equivalent write-tree (read + SHA-1 + zlib + store, one thread, src/commit.cpp:139-173) from the
+    CPU restatement, next to `vit write-tree` on the same worktree: BASELINE configs[0] whole, configs[2] sampled."""
+    import importlib.util
+    import shutil
+    import subprocess
+    import tempfile
+    spec = importlib.util.spec_from_file_location("bench_write_tree", os.path.join(HERE, "tools", "bench_write_tree.py"))
+    bwt = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bwt)
+    vit = os.path.join(HERE, "vit_amd", "bin", "vit")
+    res = {"kind": "port", "cores": 1,
+           "note": "cpu_s = the oracle's writeTree incl. deflate and loose-object files, one thread, as the reference runs; "
+                   "gpu_s = `vit write-tree` (walk + read + GPU ids + deflate/store on host threads), its own --stats total"}
+    for name, make, arg, what in (("c1", bwt.make_c1, None, "BASELINE configs[0]: 1,000 x 4 KiB in 10 directories"),
+                                  ("c3_sample", bwt.make_c3, 20000,
+                                   "a quarter of BASELINE configs[2]: 20,000 files, lognormal sizes, 3 levels")):
+        top = tempfile.mkdtemp(prefix="vit_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            wt = os.path.join(top, "wt")
+            os.makedirs(wt)
+            n, total = make(wt) if arg is None else make(wt, arg)
+            t0 = time.perf_counter()
+            root, nb, nt = O.write_tree(wt, os.path.join(top, "cpu_objects"))
+            cpu_s = time.perf_counter() - t0
+            rec = {"workload": what, "files": n, "bytes": total, "trees": nt, "cpu_s": round(cpu_s, 3),
+                   "cpu_objects_per_s": round((nb + nt) / cpu_s, 1), "root": root.hex()}
+            if os.path.exists(vit):
+                env = dict(os.environ)
+                env.setdefault("VIT_DEVICES", "0")
+                subprocess.check_call([vit, "init"], cwd=wt, stdout=subprocess.DEVNULL, env=env)
+                t0 = time.perf_counter()
+                p = subprocess.run([vit, "write-tree", "--stats"], cwd=wt, capture_output=True, env=env, timeout=300)
+                wall = time.perf_counter() - t0
+                stats = p.stderr.decode().strip().splitlines()[-1] if p.stderr else ""
+                inner = float(stats.split(" total ")[1].split()[0]) if " total " in stats else None
+                rec.update({"gpu_s": inner, "gpu_wall_s_with_process_start": round(wall, 3),
+                            "gpu_objects_per_s": round((nb + nt) / inner, 1) if inner else None,
+                            "gpu_root_matches": p.stdout.decode().strip() == root.hex(), "gpu_stats": stats})
+            res[name] = rec
+        finally:
+            shutil.rmtree(top, ignore_errors=True)
+    return res
 
 
 def main():
@@ -148,8 +287,8 @@ def main():
         dist.barrier()
 
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
+        vdist.wait_for_rank0(dist)          # CPU-side wait: this rank's GPU stays idle for rank 0's host-memory legs
+        dist.destroy_process_group()
         return
 
     steps = args.steps
@@ -186,30 +325,23 @@ def main():
                      "kernel_ms_avg": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
                      "note": "the kernel is bound by integer VALU issue, not HBM: see valu",
                      "valu": {"achieved": round(valu_tops, 2), "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
-                              "frac": round(valu_tops / VALU_PEAK_TOPS, 4), "ops_per_block": OPS_PER_BLOCK}},
+                              "frac": round(valu_tops / VALU_PEAK_TOPS, 4), "ops_per_block": OPS_PER_BLOCK,
+                              "peak_definition": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: the issue rate measured on this "
+                                                 "chip for 3-source-operand and shift/rotate instructions (533 of the 597 per "
+                                                 "block; tools/valu_ubench.hip, profiles/r02_valu_ubench.txt). 2-source "
+                                                 "add/xor alone issue at ~2x that but not in this mix (measured 4.0 "
+                                                 "cycles/instruction over the whole SHA-1 stream)"}},
         "device_status": status,
     }
+    batch = None
+    if not args.no_end_to_end:
+        try:
+            line["end_to_end_host_memory"] = end_to_end(args, world, dig)
+        except Exception as e:                                   # a side leg must not lose the measured line
+            line["end_to_end_host_memory"] = {"error": repr(e)}
+    vdist.release_ranks(dist)
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(args, dig)
-    if args.end_to_end and world == 1:
-        from vit_amd import _abi
-        m = min(n, 262144)
-        host = np.empty(m * L, dtype=np.uint8)             # the same blobs, in host memory (the library's generator)
-        fill = _abi.load().vit_synth_bytes
-        for i in range(m):
-            fill(SEED, i, host.ctypes.data + i * L, L)
-        blobs = [host[i * L:(i + 1) * L] for i in range(m)]
-        h.hash_blobs(blobs)                               # first call sizes the pinned and device staging buffers
-        runs = []
-        for _ in range(3):
-            got = h.hash_blobs(blobs)
-            runs.append((h.stat("last_total_ns"), h.stat("last_pack_ns")))
-        total_ns, pack_ns = sorted(runs)[1]
-        # time inside vit_hash_blobs (pack + H2D + kernel + D2H), without the Python argument marshalling
-        line["end_to_end_host_memory"] = {"value": round(m * L / total_ns, 3), "unit": "GB/s", "blobs": m,
-                                          "total_ms": round(total_ns / 1e6, 2), "pack_ms": round(pack_ns / 1e6, 2),
-                                          "pack_threads": min(os.cpu_count() or 1, 16),
-                                          "matches": bool((got == dig[:m]).all())}
     print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

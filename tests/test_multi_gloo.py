@@ -39,6 +39,15 @@ WORKER = textwrap.dedent("""
     slowest = vdist.max_over_ranks(dist, 1.0 + rank)     # rank 1 pretends to be slower
     summary = vdist.combine_summaries(dist, vdist.xor_summary(digests))
     dist.barrier()
+    # rank 0 works alone for a while; the other rank waits on the store, not in a collective
+    import time
+    t0 = time.time()
+    if rank == 0:
+        time.sleep(1.0)
+        vdist.release_ranks(dist)
+    else:
+        vdist.wait_for_rank0(dist, timeout_s=60)
+        assert time.time() - t0 > 0.5
     print(json.dumps({"rank": rank, "mine": mine.tolist(), "total": total, "load": load, "slowest": slowest,
                       "summary": summary.tolist(), "first": vdist.weak_first_index(rank, 1000)}), flush=True)
     dist.destroy_process_group()
@@ -99,7 +108,7 @@ def test_bench_runs_as_two_ranks_on_one_gpu():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--blobs", "200000",
-           "--dist-backend", "gloo", "--no-cpu-baseline"]
+           "--dist-backend", "gloo", "--no-cpu-baseline", "--e2e-objects", "30000"]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -108,3 +117,9 @@ def test_bench_runs_as_two_ranks_on_one_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["device_status"] == 0
     assert abs(d["objects_per_s"] - 2 * 200000 * 5 / (d["ms_per_step"] * 5e-3)) / d["objects_per_s"] < 0.01
     assert abs(d["value"] - d["objects_per_s"] * 4096 / 1e9) / d["value"] < 0.01
+    # the host-memory legs ran after the timed region, on one hasher with a queue per rank's GPU (GPU 0 twice here)
+    e = d["end_to_end_host_memory"]
+    assert e["uniform_4k"]["matches_resident_digests"]
+    m = e["mixed_slice"]
+    assert m["queues"] == 2 and m["device_ids"] == [0, 0] and m["matches"] and m["scaling"] == "strong"
+    assert m["objects_gpu"] + m["objects_host"] == 30000

@@ -872,6 +872,18 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
     host_work.reset();
     h->last_pack_ns = 0;
     for (uint64_t p : pack_ns) h->last_pack_ns = std::max(h->last_pack_ns, p);
+    // The calibration packs one cache-warm buffer; a real batch streams from
+    // DRAM on every thread at once.  Let what this call measured correct the
+    // rate the next call balances with: bytes packed over the packing time of
+    // the queue that packed longest, per thread of the budget (batches of 256 MiB and more only).
+    if (!h->pack_fixed && h->calibrated && h->last_pack_ns) {
+        uint64_t packed = 0;
+        for (uint64_t i : gpu_idx) packed += len[i];
+        if (packed >= (256ull << 20)) {
+            const double per_thread = double(packed) / (double(h->last_pack_ns) * 1e-9) / double(h->pack_threads);
+            h->pack_rate = 0.5 * h->pack_rate + 0.5 * per_thread;
+        }
+    }
     h->last_total_ns = ns_since(t0);
     if (h->trace)
         for (size_t k = 0; k < h->queues.size(); ++k)

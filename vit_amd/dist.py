@@ -66,6 +66,28 @@ def sum_over_ranks(dist, value):
     return int(t.item())
 
 
+_DONE_KEY = "vit_rank0_side_legs_done"
+
+
+def release_ranks(dist):
+    """Rank 0: tell the waiting ranks that its single-process measurements are over."""
+    if dist is None:
+        return
+    from torch.distributed.distributed_c10d import _get_default_store
+    _get_default_store().set(_DONE_KEY, "1")
+
+
+def wait_for_rank0(dist, timeout_s=3600):
+    """Other ranks: block on the rendezvous store, on the CPU, until rank 0 calls release_ranks().
+    Not a collective: a barrier on RCCL would park a spinning kernel on every waiting rank's GPU,
+    and rank 0 is meanwhile measuring ONE hasher that drives all of those GPUs."""
+    if dist is None:
+        return
+    import datetime
+    from torch.distributed.distributed_c10d import _get_default_store
+    _get_default_store().wait([_DONE_KEY], datetime.timedelta(seconds=timeout_s))
+
+
 def weak_first_index(rank, n_per_rank):
     """Weak scaling: rank r hashes synthetic objects [r*n, (r+1)*n)."""
     return rank * n_per_rank
