@@ -193,6 +193,48 @@ def test_device_binning_gives_the_host_order(hasher):
     assert hasher.device_status() == 0
 
 
+@pytest.mark.parametrize("waves", [1, 2])
+def test_software_scheduled_launch_gives_the_same_ids(hasher, waves):
+    """The persistent-wave launch (groups pulled from both ends of the binned order) forced onto batches of
+    every shape: fewer groups than resident waves, ragged last group, a long tail, launches back to back
+    (each must leave the scheduler state clean for the next), and the host pipeline's binned chunks."""
+    import vit_amd
+    rng = np.random.default_rng(500 + waves)
+    hasher.set_option("sched_waves", waves)
+    hasher.set_option("sched_min_groups", 1)
+    for n in (1, 63, 65, 1000, 70_001, 400_000):
+        lens = np.minimum(np.exp(rng.normal(np.log(1500.0), 1.5, n)), 300_000).astype(np.uint64)
+        b = hasher.synth_arena("blob", 0x5EED0088, 0, n, 0, lens=lens)
+        nb = b["nblocks"].download(np.uint32, 4 * n)
+        order_host, _ = vit_amd.bin_order(nb)
+        order = hasher.alloc(4 * n).upload(order_host)
+        hasher.set_option("sched_waves", 0)
+        want = hasher.hash_device(b, order=order).copy()
+        hasher.set_option("sched_waves", waves)
+        for _ in range(3):
+            b["digests"].upload(np.zeros(20 * n, dtype=np.uint8))
+            got = hasher.hash_device(b, order=order)
+            assert (got == want).all(), (n, int(np.nonzero((got != want).any(axis=1))[0][0]))
+        hasher.time_hash_device(b, order=order, warmup=0, iters=8)           # eight launches queued back to back
+        assert (b["digests"].download(np.uint8, 20 * n).reshape(-1, 20) == want).all()
+        for i in (0, n // 2, n - 1, int(np.argmax(lens))):
+            data = vit_amd.synth_bytes(0x5EED0088, i, int(lens[i]))
+            assert want[i].tobytes() == hashlib.sha1(b"blob %d\0" % len(data) + data).digest()
+        assert hasher.device_status() == 0
+    # through the host pipeline: several binned chunks in flight on different streams, each with a state of its own
+    lens = rng.integers(0, 20_000, size=30_000).tolist() + [300_000, 1 << 20]
+    buf = np.frombuffer(vit_amd.synth_bytes(0x5EED0089, 0, (1 << 20) + len(lens)), dtype=np.uint8)
+    blobs = [buf[i:i + L] for i, L in enumerate(lens)]
+    hasher.set_option("chunk_bytes", 4 << 20)
+    hasher.set_option("chunk_object_multiple", 0)
+    hasher.set_option("host_threshold_bytes", 0)
+    got = hasher.hash_blobs(blobs)
+    hasher.set_option("sched_waves", 0)
+    assert (hasher.hash_blobs(blobs) == got).all()
+    for i in (0, 7, len(lens) - 1):
+        assert got[i].tobytes() == hashlib.sha1(b"blob %d\0" % lens[i] + blobs[i].tobytes()).digest()
+
+
 def test_plain_sha1_of_buffers(hasher, oracle, golden_objects):
     """vit_sha1_buffers: SHA1(data, len) with no Git framing, the reference's call (src/commit.cpp:93-94)
     n at a time: FIPS 180 known answers, ragged buffers against hashlib, framed strings give object ids,

@@ -52,8 +52,19 @@ def mixed(a):
     out["bin_order_device_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
     out["device_order_equals_host_order"] = bool((d_order.download(np.uint32, 4 * a.n) == order_host).all())
     b["digests"].upload(np.zeros(20 * a.n, dtype=np.uint8))
+    h.set_option("sched_waves", 0)                         # hardware dispatch: one workgroup per 256 objects
     ms1 = h.time_hash_device(b, order=order, warmup=1, iters=a.iters)
-    d1 = b["digests"].download(np.uint8, 20 * a.n).reshape(-1, 20)
+    d1 = b["digests"].download(np.uint8, 20 * a.n).reshape(-1, 20).copy()
+    out["scheduled"] = {}
+    for waves in a.sched_waves:                            # software-scheduled: resident waves pulling groups down the order
+        for share in a.share_below:
+            h.set_option("sched_waves", waves)
+            h.set_option("sched_share_below", share)
+            b["digests"].upload(np.zeros(20 * a.n, dtype=np.uint8))
+            msw = h.time_hash_device(b, order=order, warmup=1, iters=a.iters)
+            dw = b["digests"].download(np.uint8, 20 * a.n).reshape(-1, 20)
+            out["scheduled"]["%d_waves_share_below_%d" % (waves, share)] = {
+                "ms": round(min(msw), 3), "GBps": round(float(sizes.sum()) / min(msw) / 1e6, 1), "match": bool((dw == d1).all())}
     out["match_binned_vs_unbinned"] = bool((d0 == d1).all())
     for i in (0, 1, a.n // 2, a.n - 1, int(np.argmax(sizes))):
         assert d1[i].tobytes() == git_id(vit_amd.synth_bytes(0x5EED0004, i, int(sizes[i]))), i
@@ -190,6 +201,8 @@ def main():
     m.add_argument("--clip", type=int, default=32 << 20)
     m.add_argument("--iters", type=int, default=3)
     m.add_argument("--kernel", type=int, default=0)
+    m.add_argument("--sched-waves", type=int, nargs="*", default=[1, 3, 5])
+    m.add_argument("--share-below", type=int, nargs="*", default=[0, 32, 128, 512, 100000])
     s = sub.add_parser("skew")
     s.add_argument("--giants", type=int, default=4)
     s.add_argument("--giant-bytes", type=int, default=2 << 30)

@@ -11,6 +11,10 @@ import vit_amd  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
 
 h = vit_amd.Hasher((0,))
+# VIT_SCHED_WAVES=0: hardware dispatch; 1..5: the software-scheduled launch with that many waves per SIMD
+for opt, env in (("sched_waves", "VIT_SCHED_WAVES"), ("sched_share_below", "VIT_SHARE_BELOW")):
+    if os.environ.get(env) is not None:
+        h.set_option(opt, int(os.environ[env]))
 rng = np.random.default_rng(0x5EED0004)
 sizes = np.exp(rng.normal(np.log(4500.0), 1.55, n))
 sizes = np.minimum(sizes * (15000.0 / sizes.mean()), 262144).astype(np.uint64)
@@ -54,6 +58,14 @@ for k, e, m in zip(key, end, mx):
 ends = np.array(sorted(last.values())); works = np.array([work[k] for k in last])
 print("SIMD finish time us: min %.0f p10 %.0f median %.0f p90 %.0f max %.0f" % (ends[0], np.percentile(ends, 10), np.median(ends), np.percentile(ends, 90), ends[-1]))
 print("wave-blocks per SIMD: min %d median %d max %d  (sum %d)" % (works.min(), np.median(works), works.max(), works.sum()))
+cnts = np.array([cnt[k] for k in last])
+print("groups per SIMD: min %d median %d max %d" % (cnts.min(), np.median(cnts), cnts.max()))
+# how many groups a SIMD runs at once, sampled at a few instants
+for t in (50, 200, 400, 800, 1000):
+    live = collections.Counter(key[(start <= t) & (end > t)].tolist())
+    if live:
+        v = np.array(list(live.values()))
+        print("at %4d us: %d SIMDs busy, groups in flight per busy SIMD: min %d median %d max %d" % (t, len(v), v.min(), np.median(v), v.max()))
 # the waves that end last
 idx = np.argsort(-end)[:12]
 for i in idx:

@@ -69,6 +69,8 @@ struct Queue {
     uint32_t* d_status = nullptr;                          // device: word 0 = STATUS_* bits; bytes 1024.. = calibration output
     uint32_t* h_status = nullptr;                          // pinned: where vit_device_status reads that word to
     uint32_t  status_seen = 0;                             // bits the chunks of host-memory calls have brought back
+    vit::SchedState* d_sched = nullptr;                    // device: kSchedStates states of the software-scheduled launch,
+    uint32_t  sched_next = 0;                              // used in turn (a launch leaves its state all zero again)
     void*     scratch = nullptr;                           // this DEVICE's address of the kernels' file-scope scratch array
                                                            // (vit_hash_arena_device_static); shared by every queue on the device
     uint64_t  chunks_this_call = 0;
@@ -85,6 +87,11 @@ struct Queue {
 
 constexpr uint64_t kStatusBytes = 4096;                   // allocation behind Queue::d_status
 constexpr uint64_t kCalibOut = 1024;                      // byte offset of the calibration kernel's output in it
+// Scheduler states per queue.  A launch owns its state until it ends.  The three
+// staging sets have one each (a set has at most one launch in flight); launches
+// on device-resident arenas take the others in turn, so two of those would meet
+// in one state only with more than kSchedStates - 3 of them in flight at once.
+constexpr uint32_t kSchedStates = 16;
 
 }  // namespace
 
@@ -99,6 +106,11 @@ struct vit_hasher {
     uint64_t chunk_bytes = 64ull << 20;
     uint64_t chunk_object_multiple = 8192;
     bool trace = false;
+    // Batches in binned order of at least sched_min_groups 64-object groups go through the
+    // software-scheduled launch (kernels.hip) when the LDS kernel is selected; 0 waves = off.
+    uint32_t sched_waves = 1;                             // resident waves per SIMD of that launch (1 or 2)
+    uint32_t sched_min_groups = 4096;
+    uint32_t sched_share_below = 128;                     // blocks: a SIMD's spare waves work only beside a leader group this short
     int pack_threads = 8;                                 // the host thread budget of a call, helpers included
     std::unique_ptr<vit::WorkPool> pool;
     // Rates the auto policy balances with, bytes per second; 0 = not measured
@@ -264,6 +276,19 @@ vit::DeviceBatch make_batch(const Queue& q, const void* d_arena, uint64_t arena_
     return b;
 }
 
+// The SHA-1 launch of a batch: software-scheduled when the batch is in binned
+// order and large enough to fill the resident grid several times, else plain.
+// staging_set: 0..2 for a chunk of that staging set, -1 for a caller's device-resident arena.
+hipError_t launch_hash(vit_hasher* h, Queue& q, const vit::DeviceBatch& b, hipStream_t stream, int staging_set)
+{
+    const uint64_t groups = (uint64_t(b.n) + 63) / 64;
+    if (h->kernel == VIT_KERNEL_LDS && b.order && h->sched_waves && groups >= h->sched_min_groups) {
+        const uint32_t state = staging_set >= 0 ? uint32_t(staging_set) : 3u + q.sched_next++ % (kSchedStates - 3u);
+        return vit::launch_sha1_sched(b, &q.d_sched[state], h->sched_waves, h->sched_share_below, stream);
+    }
+    return vit::launch_sha1(vit::KernelVariant(h->kernel), b, stream);
+}
+
 // Collect a finished chunk: wait for it, scatter its digests to the caller and
 // note the status word it brought back.
 int retire(Queue& q, Staging& s, uint8_t* digests)
@@ -319,10 +344,8 @@ int launch_chunk(Queue& q, vit_hasher* h, Staging& s, hipStream_t stream, const 
     HIP_TRYQ(q, hipMemcpyAsync(s.d_arena, src, bytes, hipMemcpyHostToDevice, stream));
     HIP_TRYQ(q, hipMemcpyAsync(s.d_meta, s.h_meta, meta_bytes + (binned ? meta_bytes / 3 : 0), hipMemcpyHostToDevice, stream));
     if (trace) HIP_TRYQ(q, hipEventRecord(s.mark[1], stream));
-    HIP_TRYQ(q, vit::launch_sha1(vit::KernelVariant(h->kernel),
-                                 make_batch(q, s.d_arena, bytes, s.d_off, s.d_nb, binned ? s.d_order : nullptr, cnt,
-                                            s.d_dig),
-                                 stream));
+    HIP_TRYQ(q, launch_hash(h, q, make_batch(q, s.d_arena, bytes, s.d_off, s.d_nb, binned ? s.d_order : nullptr, cnt,
+                                             s.d_dig), stream, int(&s - q.st)));
     if (trace) HIP_TRYQ(q, hipEventRecord(s.mark[2], stream));
     HIP_TRYQ(q, hipMemcpyAsync(s.h_dig, s.d_dig, cnt * 20, hipMemcpyDeviceToHost, stream));
     HIP_TRYQ(q, hipMemcpyAsync(s.h_status, q.d_status, 4, hipMemcpyDeviceToHost, stream));
@@ -634,6 +657,8 @@ int vit_hasher_create(const int* device_ids, int n_devices, vit_hasher** out)
             if (r == hipSuccess) r = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
         if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void**>(&q.d_status), kStatusBytes);
         if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void**>(&q.h_status), 64, hipHostMallocDefault);
+        if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void**>(&q.d_sched), sizeof(vit::SchedState) * kSchedStates);
+        if (r == hipSuccess) r = hipMemsetAsync(q.d_sched, 0, sizeof(vit::SchedState) * kSchedStates, q.stream[0]);
         // The kernels run on non-blocking streams, which the null stream does not
         // order with: clear the word on the stream that will use it, and wait.
         if (r == hipSuccess) r = hipMemsetAsync(q.d_status, 0, kStatusBytes, q.stream[0]);
@@ -672,6 +697,7 @@ void vit_hasher_destroy(vit_hasher* h)
         for (Staging& s : q.st) free_staging(s);
         if (q.d_status) (void)hipFree(q.d_status);
         if (q.h_status) (void)hipHostFree(q.h_status);
+        if (q.d_sched) (void)hipFree(q.d_sched);
         if (q.ev_a) (void)hipEventDestroy(q.ev_a);
         if (q.ev_b) (void)hipEventDestroy(q.ev_b);
         if (q.sort_scratch) (void)hipFree(q.sort_scratch);
@@ -709,6 +735,9 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     else if (k == "copy_rate") rate(h->copy_rate, h->copy_fixed);
     else if (k == "pack_rate") rate(h->pack_rate, h->pack_fixed);
     else if (k == "debug_fail_at_chunk") h->fail_at_chunk = value;
+    else if (k == "sched_waves") h->sched_waves = uint32_t(value > 8 ? 8 : value);
+    else if (k == "sched_share_below") h->sched_share_below = uint32_t(value > 0xFFFFFFFEull ? 0xFFFFFFFEu : value);
+    else if (k == "sched_min_groups") h->sched_min_groups = uint32_t(value > 0xFFFFFFFFull ? 0xFFFFFFFFu : value);
     else return fail(h, VIT_ERR_ARG, "unknown option '%s'", name);
     return VIT_OK;
     VIT_NOEXCEPT_END(h)
@@ -1050,8 +1079,7 @@ int vit_hash_arena_device(vit_hasher* h, int dev, const void* d_arena, uint64_t 
     if (reinterpret_cast<uintptr_t>(d_arena) & 15) return fail(h, VIT_ERR_RANGE, "arena not 16-byte aligned");
     HIP_TRY(h, hipSetDevice(q->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : q->stream[0];
-    HIP_TRY(h, vit::launch_sha1(vit::KernelVariant(h->kernel),
-                                make_batch(*q, d_arena, arena_bytes, d_offsets, d_nblocks, d_order, n, d_digests), s));
+    HIP_TRY(h, launch_hash(h, *q, make_batch(*q, d_arena, arena_bytes, d_offsets, d_nblocks, d_order, n, d_digests), s, -1));
     ++h->launches; h->objects_gpu += n;
     return VIT_OK;
 }
@@ -1073,9 +1101,10 @@ int vit_hash_arena_device_static(vit_hasher* h, int dev, const void* d_arena, ui
     if (reinterpret_cast<uintptr_t>(d_arena) & 15) return fail(h, VIT_ERR_RANGE, "arena not 16-byte aligned");
     HIP_TRY(h, hipSetDevice(q->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : q->stream[0];
+    const bool sched = h->kernel == VIT_KERNEL_LDS && h->sched_waves && (n + 63) / 64 >= h->sched_min_groups;
     HIP_TRY(h, vit::launch_sha1_static(vit::KernelVariant(h->kernel),
                                        make_batch(*q, d_arena, arena_bytes, d_offsets, d_nblocks, nullptr, n, d_digests),
-                                       q->scratch, s));
+                                       q->scratch, sched ? h->sched_waves : 0, h->sched_share_below, s));
     ++h->launches; h->objects_gpu += n;
     return VIT_OK;
 }

@@ -40,6 +40,23 @@ hipError_t launch_sha1(KernelVariant v, const DeviceBatch& b, hipStream_t stream
 // Launch shape for n objects (n up to 2^32 - 1): workgroups, threads per workgroup.
 void launch_shape(KernelVariant v, uint64_t n, uint32_t* blocks, uint32_t* threads);
 
+// The software-scheduled launch for batches in binned order (b.order lists the objects longest first; without
+// an order the batch itself is taken to be in that order): a fixed grid of resident waves pulls 64-object
+// groups down that order, one leader wave per SIMD always, the SIMD's other waves only while the leader is on
+// a group of at most share_below blocks (see kernels.hip).  `state` is device memory, all zero before the
+// first launch that uses it; a launch leaves it all zero again, so launches that follow each other on a
+// stream may share one, launches that overlap may not.
+constexpr uint32_t SCHED_SIMD_KEYS = 8192;
+struct SchedState {
+    uint32_t next;                        // next group to hand out
+    uint32_t exited;                      // waves that have left
+    uint32_t pad[14];
+    uint32_t simd_waves[SCHED_SIMD_KEYS]; // waves registered on each physical SIMD
+    uint32_t simd_len[SCHED_SIMD_KEYS];   // 1 + length in blocks of the group that SIMD's leader is on; 0 = none
+};
+hipError_t launch_sha1_sched(const DeviceBatch& b, SchedState* state, uint32_t waves_per_simd, uint32_t share_below,
+                             hipStream_t stream);
+
 // Synthetic framed arena, generated on the device (benchmark and full-size
 // parity inputs; the reference has no benchmark data of its own).
 // Content byte j of object i is byte j of the counter-based splitmix64 stream
@@ -74,7 +91,8 @@ hipError_t bin_order_device(const uint32_t* d_nblocks, uint32_t n, uint32_t* d_o
 constexpr uint32_t STATIC_MAX_OBJECTS = 1u << 21;
 hipError_t static_scratch_address(void** out);        // hipGetSymbolAddress for the current device
 uint64_t static_scratch_bytes();
-hipError_t launch_sha1_static(KernelVariant v, DeviceBatch b, void* scratch_ptr, hipStream_t stream);
+hipError_t launch_sha1_static(KernelVariant v, DeviceBatch b, void* scratch_ptr, uint32_t sched_waves,
+                              uint32_t sched_share_below, hipStream_t stream);
 
 // Compute-only ceiling: every lane runs `blocks_per_lane` SHA-1 compressions on
 // register-resident data (no loads in the loop).  out: one dword per lane.

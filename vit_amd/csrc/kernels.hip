@@ -191,20 +191,17 @@ __device__ __forceinline__ void far_stages(const uint8_t* arena, uint8_t* stage,
 // WPB waves share a workgroup only to get past the limit on resident
 // workgroups per CU (one-wave workgroups filled 3.6 of the 5 wave slots per
 // SIMD); each wave still works on its own 64 objects and its own slice of LDS.
-template <int BPS, int WPB>
-__global__ __launch_bounds__(64 * WPB, BPS == 4 ? 2 : (BPS == 1 ? 4 : 5)) void sha1_lds_kernel(DeviceBatch b)
+// One wave hashes the 64 objects of slots [64*group, 64*group + 64) through its
+// own 64*64*BPS-byte stage buffer in LDS.
+template <int BPS>
+__device__ __forceinline__ void hash_group(const DeviceBatch& b, uint8_t* const stage, uint32_t group, uint32_t lane)
 {
     constexpr int LPO  = 4 * BPS;        // lanes per object per instruction == instructions per stage
     constexpr int OPI  = 64 / LPO;       // objects per instruction
     constexpr int ROWB = 64 * BPS;       // bytes per object per stage
     constexpr int RP   = 16 / LPO > 0 ? 16 / LPO : 1;   // rows per 256-byte bank line
 
-    __shared__ __attribute__((aligned(16))) uint8_t stage_all[WPB][64 * ROWB];
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint8_t* const stage = stage_all[wave];
-    const uint32_t slot = (blockIdx.x * WPB + wave) * 64u + lane;
+    const uint32_t slot = group * 64u + lane;
 
     const uint64_t trace_t0 = b.wave_trace ? wall_clock64() : 0;
     const Slot me = resolve_slot(b, slot);
@@ -260,7 +257,7 @@ __global__ __launch_bounds__(64 * WPB, BPS == 4 ? 2 : (BPS == 1 ? 4 : 5)) void s
     if (!near) {
         far_stages<BPS>(b.arena, stage, foff, lim, my_row, my_sw, my_nb, nst, h);
         if (owns) store_digest(b.digests, idx, h);
-        if (b.wave_trace && lane == 0) trace_wave(b.wave_trace, slot / 64u, trace_t0, max_nb | (1ull << 40));
+        if (b.wave_trace && lane == 0) trace_wave(b.wave_trace, group, trace_t0, max_nb | (1ull << 40));
         return;
     }
 
@@ -330,7 +327,129 @@ __global__ __launch_bounds__(64 * WPB, BPS == 4 ? 2 : (BPS == 1 ? 4 : 5)) void s
     for (; t + 1 < full_stages; ++t) stage_body(t, std::true_type());
     for (; t < nst; ++t) stage_body(t, std::false_type());
     if (owns) store_digest(b.digests, idx, h);
-    if (b.wave_trace && lane == 0) trace_wave(b.wave_trace, slot / 64u, trace_t0, max_nb);
+    if (b.wave_trace && lane == 0) trace_wave(b.wave_trace, group, trace_t0, max_nb);
+}
+
+template <int BPS, int WPB>
+__global__ __launch_bounds__(64 * WPB, BPS == 4 ? 2 : (BPS == 1 ? 4 : 5)) void sha1_lds_kernel(DeviceBatch b)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[WPB][64 * 64 * BPS];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    hash_group<BPS>(b, stage_all[wave], blockIdx.x * WPB + wave, lane);
+}
+
+// ------------------------------------------------ software-scheduled launch --
+// For batches in binned order (group 0 holds the longest objects).  The hardware
+// dispatcher hands out workgroups as wave slots free up, and a SIMD shares its
+// issue slots among its resident waves: on a batch with a long tail the SIMD
+// that holds the longest wave also gets four of the next-longest, the long wave
+// then runs at a fraction of the SIMD's rate, and the launch ends when that
+// SIMD does (measured on a 17 GB skewed batch: 6.9 to 7.1 ms where the chip's
+// issue capacity allows 4.7).
+//
+// Here the grid is a fixed set of resident waves, one per SIMD by default, that
+// pull 64-object groups from ONE cursor running down the binned order:
+//   * the first wave to arrive on a physical SIMD is that SIMD's LEADER.  It
+//     pulls the next group whenever it is free: the longest groups go to
+//     different SIMDs, and a SIMD takes its next long group only when it has
+//     finished the last (list scheduling of a sorted list, i.e. longest
+//     processing time first).  Every SIMD then ends within 1 % of the others.
+//   * any other wave that lands on the SIMD is a SPARE.  A spare pulls a group
+//     only while its leader is on a group of at most `share_below` blocks and
+//     otherwise sleeps (long sleeps: spares that polled every 2 us cost the
+//     leaders 12 %).  Spares exist so that an uneven placement of the grid by
+//     the hardware cannot leave two long groups on one SIMD; measured, they do
+//     not pay for themselves as helpers (two waves per SIMD: 5.76 ms against
+//     5.60 ms for leaders alone), so the default launches none.
+// What bounds the leaders-only launch is the rate of ONE wave on a SIMD: a lone
+// wave issues an instruction every 4.8 cycles (1.32 us per block), not every
+// 4.0 as five waves together do; a second stage of DMA in flight for such
+// waves was tried and changed nothing, the stalls are between dependent vector
+// instructions, not memory.  A 4097-block group cannot run on two waves (one
+// SHA-1 stream per lane), so 4097 x 1.32 us = 5.4 ms is this batch's floor.
+// Every wave leaves once the cursor has passed the last group, which every wave
+// observes.  The state returns to all-zero at the end of the launch (each wave
+// unregisters, each leader withdraws its length, the last wave out clears the
+// cursor), ready for the next launch that uses it.
+__device__ __forceinline__ uint32_t physical_simd()
+{
+    const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID: SIMD [5:4], CU [11:8], SH [12], SE [15:13]
+    const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;
+    const uint32_t simd = (hw >> 4) & 3u, cu = (hw >> 8) & 0xFu, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
+    return ((xcc * 8u + se) * 2u + sh) * 64u + cu * 4u + simd;                   // < SCHED_SIMD_KEYS
+}
+
+__device__ __forceinline__ uint32_t peek(const uint32_t* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int BPS, int WPB>
+__global__ __launch_bounds__(64 * WPB, 2) void sha1_sched_kernel(DeviceBatch b, SchedState* st, uint32_t groups,
+                                                                 uint32_t nwaves, uint32_t share_below)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t stage_all[WPB][64 * 64 * BPS];
+    const uint32_t lane = threadIdx.x & 63u;
+    uint8_t* const stage = stage_all[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+    const uint32_t key = physical_simd();
+    uint32_t rank = 0;
+    if (lane == 0) rank = atomicAdd(&st->simd_waves[key], 1u);
+    const bool leader = __builtin_amdgcn_readfirstlane(rank) == 0;
+    if (leader) __builtin_amdgcn_s_setprio(3);
+    for (;;) {
+        if (!leader) {
+            // simd_len: 0 = the leader has not published yet (or has left); else its group's length + 1
+            bool go = false;
+            for (;;) {
+                if (peek(&st->next) >= groups) break;
+                const uint32_t len1 = peek(&st->simd_len[key]);
+                if (len1 != 0 && len1 - 1u <= share_below) { go = true; break; }
+                for (int z = 0; z < 16; ++z) __builtin_amdgcn_s_sleep(127);
+            }
+            if (!go) break;
+        }
+        uint32_t g = 0xFFFFFFFFu;
+        if (lane == 0) {
+            const uint32_t c = atomicAdd(&st->next, 1u);
+            if (c < groups) g = c;
+        }
+        g = __builtin_amdgcn_readfirstlane(g);
+        if (g == 0xFFFFFFFFu) break;
+        if (leader && lane == 0) {
+            uint32_t first = g * 64u;                      // binned order: the group's first object is its longest
+            if (b.order) first = b.order[first];
+            const uint32_t len = first < b.n ? b.nblocks[first] : 0u;
+            atomicExch(&st->simd_len[key], len == 0xFFFFFFFFu ? len : len + 1u);
+        }
+        hash_group<BPS>(b, stage, g, lane);
+        wave_lds_sync();                 // the next group's tables go where this group's last stage was read from
+    }
+    if (lane == 0) {
+        if (leader) atomicExch(&st->simd_len[key], 0u);
+        atomicSub(&st->simd_waves[key], 1u);
+        __threadfence();
+        if (atomicAdd(&st->exited, 1u) == nwaves - 1u) { atomicExch(&st->next, 0u); atomicExch(&st->exited, 0u); }
+    }
+}
+
+hipError_t launch_sha1_sched(const DeviceBatch& b, SchedState* state, uint32_t waves_per_simd, uint32_t share_below,
+                             hipStream_t stream)
+{
+    if (b.n == 0) return hipSuccess;
+    if (!state) return hipErrorInvalidValue;
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return e;
+    const uint32_t groups = uint32_t((uint64_t(b.n) + 63u) / 64u);
+    if (waves_per_simd == 0 || waves_per_simd > 2) waves_per_simd = 2;
+    // one four-wave workgroup per CU and wave-per-SIMD; never more waves than groups
+    uint32_t wgs = uint32_t(cus) * waves_per_simd;
+    if (wgs > (groups + 3u) / 4u) wgs = (groups + 3u) / 4u;
+    const uint32_t nwaves = wgs * 4u;
+    hipLaunchKernelGGL((sha1_sched_kernel<2, 4>), dim3(wgs), dim3(256), 0, stream, b, state, groups, nwaves, share_below);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------- lane-direct --
@@ -517,7 +636,8 @@ constexpr uint32_t kBinItems = 4;                   // objects per thread in the
 constexpr uint64_t kScratchStatus  = 0;             // u32 status word (STATUS_* bits)
 constexpr uint64_t kScratchHist    = 256;           // u32[kBins]  histogram
 constexpr uint64_t kScratchCursor  = 256 + 4096;    // u32[kBins]  next free position per bucket
-constexpr uint64_t kScratchOrder   = 256 + 8192;    // u32[STATIC_MAX_OBJECTS]
+constexpr uint64_t kScratchSched   = 256 + 8192;    // SchedState of the software-scheduled launch
+constexpr uint64_t kScratchOrder   = kScratchSched + ((sizeof(SchedState) + 255) / 256) * 256;   // u32[STATIC_MAX_OBJECTS]
 constexpr uint64_t kScratchBytes   = kScratchOrder + 4ull * STATIC_MAX_OBJECTS;
 static_assert(kBins * 4 <= 4096, "histogram and cursor regions are 4 KiB each");
 
@@ -603,7 +723,8 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const uint32_t* nblock
     }
 }
 
-hipError_t launch_sha1_static(KernelVariant v, DeviceBatch b, void* scratch_ptr, hipStream_t stream)
+hipError_t launch_sha1_static(KernelVariant v, DeviceBatch b, void* scratch_ptr, uint32_t sched_waves,
+                              uint32_t sched_share_below, hipStream_t stream)
 {
     if (b.n == 0) return hipSuccess;
     if (b.n > STATIC_MAX_OBJECTS || !scratch_ptr) return hipErrorInvalidValue;
@@ -622,7 +743,11 @@ hipError_t launch_sha1_static(KernelVariant v, DeviceBatch b, void* scratch_ptr,
     if ((e = hipGetLastError()) != hipSuccess) return e;
     b.order = order;
     b.status = reinterpret_cast<uint32_t*>(s + kScratchStatus);
-    return launch_sha1(v, b, stream);
+    if (!sched_waves) return launch_sha1(v, b, stream);
+    // The scheduler's state must be all zero at launch: a launch leaves it so, but a
+    // launch that was cut short (device reset, aborted stream) would not have.
+    if ((e = hipMemsetAsync(s + kScratchSched, 0, sizeof(SchedState), stream)) != hipSuccess) return e;
+    return launch_sha1_sched(b, reinterpret_cast<SchedState*>(s + kScratchSched), sched_waves, sched_share_below, stream);
 }
 
 // --------------------------------------------------------- compute ceiling --
