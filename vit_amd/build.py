@@ -6,6 +6,7 @@
 Outputs (git-ignored, shipped to the GPU box with the tree):
     vit_amd/libvit_hash.so    C ABI of include/vit_hash.h (kernels + host pipeline)
     vit_amd/bin/vit           hash-object / write-tree front end (C++ object store)
+    vit_amd/bin/option_a_driver   test program: the reference's free functions over this object store
 """
 import os
 import shutil
@@ -17,6 +18,8 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libvit_hash.so")
 CLI = os.path.join(HERE, "bin", "vit")
+DRIVER = os.path.join(HERE, "bin", "option_a_driver")
+DRIVER_SOURCE = os.path.join(ROOT, "tests", "option_a_driver.cpp")
 
 LIB_SOURCES = ["kernels.hip", "hasher.cpp", "packer.cpp", "sha1_host.cpp"]
 CLI_SOURCES = ["object_store.cpp", "change_detect.cpp", "vit_cli.cpp"]
@@ -67,9 +70,27 @@ def build_cli(force=False, verbose=False):
     return CLI
 
 
+def build_driver(force=False, verbose=False):
+    """tests/option_a_driver.cpp: a caller of the reference's free functions linked against object_store.cpp
+    (the drop-in of INTEGRATION.md, Option A), for tests/test_option_a.py."""
+    srcs = [DRIVER_SOURCE, os.path.join(CSRC, "object_store.cpp")]
+    if not os.path.exists(DRIVER_SOURCE):
+        return None
+    if not force and not _stale(DRIVER, srcs) and os.path.getmtime(DRIVER) >= os.path.getmtime(LIB):
+        return DRIVER
+    os.makedirs(os.path.dirname(DRIVER), exist_ok=True)
+    cmd = [_hipcc()] + COMMON + ["-I" + CSRC, "-x", "c++", "-o", DRIVER] + srcs + [
+        "-L" + HERE, "-lvit_hash", "-Wl,-rpath,$ORIGIN/..", "-lz", "-lpthread"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return DRIVER
+
+
 def build_all(force=False, verbose=False):
     build_lib(force, verbose)
     build_cli(force, verbose)
+    build_driver(force, verbose)
 
 
 if __name__ == "__main__":

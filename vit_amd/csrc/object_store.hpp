@@ -11,11 +11,15 @@
 // then assembles the trees bottom-up, one batch per depth level, while a host
 // thread pool deflates and stores the objects.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <ctime>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
+
+#include "work_pool.h"
 
 struct vit_hasher;
 
@@ -31,6 +35,8 @@ namespace vit {
 struct StoreStats {
     uint64_t blobs = 0, trees = 0, bytes = 0;
     uint64_t skipped = 0;                      // objects already in the store (not deflated or written again)
+    // writeTree overlaps its stages: read_s = what the hashing thread waited for file reads, hash_s = GPU batches
+    // (pack + copy + kernel + read-back), deflate_store_s = from the first batch's hand-over to the last object on disk
     double walk_s = 0, read_s = 0, hash_s = 0, deflate_store_s = 0, total_s = 0;
 };
 
@@ -43,8 +49,9 @@ public:
     ObjectStore(const ObjectStore&) = delete;
     ObjectStore& operator=(const ObjectStore&) = delete;
 
-    // false (with the reason on std::cerr) when no GPU hasher could be created.
-    bool ok() const { return hasher_ != nullptr; }
+    // false (with the reason on std::cerr) when no GPU hasher could be created.  The hasher is created by
+    // the first call that needs ids; readObject / readObjectContent never need it.
+    bool ok() { return ensureHasher(); }
 
     // reference src/commit.cpp:88-114 / :116
     std::string writeObject(const std::string& type, const std::string& content);
@@ -78,19 +85,31 @@ public:
     // files are ignored; the id is then what `git add -A && git write-tree` gives on a worktree without ignore rules.
     void setGitTreeRules(bool on) { git_rules_ = on; }
     void setIoThreads(int n) { io_threads_ = n < 1 ? 1 : n; }
-    void setBatchBytes(uint64_t b) { batch_bytes_ = b; }
+    void setBatchBytes(uint64_t b) { batch_bytes_ = b < 1 ? 1 : b; }
     const StoreStats& lastStats() const { return stats_; }
-    vit_hasher* hasher() const { return hasher_; }
+    vit_hasher* hasher() { return ensureHasher() ? hasher_ : nullptr; }
     std::string objectPath(const std::string& hash) const;
 
 private:
+    struct StoreOutcome { std::atomic<int> failed{0}; std::atomic<uint64_t> skipped{0}; };   // 1 compression, 2 write
+    bool ensureHasher();
+    WorkPool& pool();
+    WorkPool::Ticket storeAsync(const std::string& type, const std::vector<std::string>& contents,
+                                const std::vector<uint8_t>& raw, StoreOutcome& outcome);
+    bool storeFinished(StoreOutcome& outcome);
+
     std::string objects_dir_;
+    std::vector<int> devices_;
+    std::unique_ptr<WorkPool> pool_;
+    bool hasher_failed_ = false;
     vit_hasher* hasher_ = nullptr;
     bool store_ = true;
     bool skip_existing_ = true;
     bool git_rules_ = false;
     int io_threads_ = 8;
-    uint64_t batch_bytes_ = 1ull << 30;
+    // Blobs per hashing batch, by bytes.  128 MiB: a dozen or more batches on a worktree of gigabytes, so that
+    // reading, hashing and storing overlap, and three batches of contents in memory at most.
+    uint64_t batch_bytes_ = 128ull << 20;
     StoreStats stats_;
 };
 

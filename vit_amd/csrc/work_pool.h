@@ -1,17 +1,17 @@
-// work_pool.h — the hasher's ONE set of host worker threads.
+// work_pool.h — a fixed set of worker threads serving groups of indexed tasks
+// at two priorities.  Two users, each with ONE pool of its own sized to the
+// cores, whatever the number of GPUs:
+//   * the hasher (hasher.cpp): packing staging chunks for every device queue
+//     (high priority: short tasks that keep a copy engine fed) and the SHA-1
+//     streams of the objects kept off the GPU (low priority: long tasks nobody
+//     waits on until the end of the batch);
+//   * the object store (object_store.cpp): file reads of the next batch (high:
+//     they feed the GPU) and deflate + loose-object writes (low: most of the work).
 //
-// Everything on the host side of a batch that is worth a thread runs here:
-// packing staging chunks for every device queue, and the SHA-1 streams of the
-// objects kept off the GPU.  One pool per hasher, sized to the cores once
-// (option "pack_threads"), shared by all device queues: the number of live
-// worker threads does not grow with the number of GPUs.
-//
-// Work comes as GROUPS of n indexed tasks with one of two priorities.  Workers
-// always serve the oldest high-priority group first (chunk packing: short tasks
-// that keep a copy engine fed), then the oldest low-priority group (host-lane
-// objects: long tasks nobody waits on until the end of the batch).  The thread
-// that waits for a group helps with that group's tasks, so a group completes
-// even on a pool of zero threads and a waiting device-queue thread is not idle.
+// Workers always serve the oldest high-priority group first, then the oldest
+// low-priority group.  The thread that waits for a group helps with that group's
+// tasks, so a group completes even on a pool of zero threads and a waiting
+// thread is not idle.
 #pragma once
 #include <atomic>
 #include <condition_variable>
@@ -37,7 +37,11 @@ public:
     };
     using Ticket = std::shared_ptr<Group>;
 
-    explicit WorkPool(int threads) { resize(threads); }
+    // on_thread_start, when given, runs once at the start of every worker thread.
+    explicit WorkPool(int threads, std::function<void()> on_thread_start = nullptr) : on_start_(std::move(on_thread_start))
+    {
+        resize(threads);
+    }
     ~WorkPool() { stop(); }
     WorkPool(const WorkPool&) = delete;
     WorkPool& operator=(const WorkPool&) = delete;
@@ -101,6 +105,7 @@ private:
 
     void work()
     {
+        if (on_start_) on_start_();
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
             wake_.wait(lk, [this] { return stop_ || !open_[HIGH].empty() || !open_[LOW].empty(); });
@@ -127,6 +132,7 @@ private:
         workers_.clear();
     }
 
+    std::function<void()> on_start_;
     std::vector<std::thread> workers_;
     std::deque<Ticket> open_[2];
     std::mutex m_;
