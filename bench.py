@@ -137,6 +137,9 @@ def end_to_end(args, world, resident_digests):
         ptrs = (offs[:m] + np.uint64(buf.ctypes.data)).astype(np.uint64)
         payload = int(offs[-1])
         with vit_amd.Hasher(ids) as h:
+            # 16 host threads per GPU of the run (the CPU share a GPU comes with on the test machines), within the
+            # CPUs this process may run on
+            h.set_option("pack_threads", max(2, min(len(os.sched_getaffinity(0)), 16 * len(ids))))
             dig, (total_ns, pack_ns, on_gpu, on_host, bytes_host, h2d) = time_host_batch(h, ptrs, sizes, m)
             rates = {k: h.stat(k) for k in ("lane_rate", "core_rate", "copy_rate", "pack_rate")}
             threads = h.stat("pool_threads") + (len(ids) if len(ids) > 1 else 1)

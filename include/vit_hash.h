@@ -90,6 +90,15 @@ int vit_hasher_device_count(const vit_hasher *h);
  *                         what "host_auto" balances with.  They are measured on this
  *                         machine the first time a batch needs them (a few ms);
  *                         setting one fixes it, 0 has it measured again
+ *  "sched_waves"          resident waves per SIMD of the software-scheduled launch that batches in
+ *                         binned order (an order array is given, or computed by the library)
+ *                         of at least "sched_min_groups" 64-object groups take: a fixed grid
+ *                         of waves pulls groups longest-first, one leader wave per SIMD, so a
+ *                         long object has its SIMD to itself (default 1; 2 adds a spare wave
+ *                         per SIMD; 0 = always the hardware dispatcher)
+ *  "sched_min_groups"     default 4096
+ *  "sched_share_below"    a spare wave works only while its SIMD's leader is on a group of at
+ *                         most this many blocks (default 128)
  *  "debug_fail_at_chunk"  tests only: the N-th staged chunk of every later call fails
  *                         as if a HIP call had (0 = off)
  *  "trace"                1: vit_hash_objects prints one line per staged
@@ -187,7 +196,9 @@ int vit_bin_order(const uint32_t *nblocks, uint64_t n, uint32_t *order);
 /* The same permutation computed on the device, for arenas whose block counts
  * never were in host memory: d_nblocks and d_order are device pointers on
  * queue `dev`; asynchronous on `stream` (NULL = the queue's own).  The library
- * keeps the sort's scratch memory (about 8 bytes per object) with the queue. */
+ * keeps the sort's scratch memory (about 8 bytes per object) with the queue
+ * (it allocates on first use and when n grows: see
+ * vit_hash_arena_device_static for a launch that bins without allocating). */
 int vit_bin_order_device(vit_hasher *h, int dev, const uint32_t *d_nblocks, uint64_t n,
                          uint32_t *d_order, void *stream);
 
@@ -217,7 +228,9 @@ int vit_hash_arena(vit_hasher *h, int dev, const void *arena, uint64_t arena_byt
  * memory.  Asynchronous on `stream` (a hipStream_t; NULL = the queue's own
  * stream).  Input that would read outside the arena is not hashed; the kernel
  * raises a status bit instead (vit_device_status).  This is the launch the
- * throughput benchmark times. */
+ * throughput benchmark times.  With d_order and at least "sched_min_groups"
+ * groups it is the software-scheduled launch; of those, a queue expects at
+ * most 13 in flight at once (each holds one of the queue's scheduler states). */
 int vit_hash_arena_device(vit_hasher *h, int dev, const void *d_arena, uint64_t arena_bytes,
                           const uint64_t *d_offsets, const uint32_t *d_nblocks,
                           const uint32_t *d_order, uint64_t n, uint8_t *d_digests,

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak: random batches through vit_hash_blobs / vit_sha1_buffers under random pipeline settings
-(chunk sizes, host-lane thresholds, one or two queues on GPU 0, both kernels), every id compared with
+(chunk sizes, host-lane thresholds, thread budget, hardware or software scheduling of binned chunks, one or two
+queues on GPU 0, both kernels), device-resident batches through the binning entry point that allocates nothing, every id compared with
 hashlib, for a given number of seconds.  Prints one JSON line; exits non-zero at the first mismatch."""
 import hashlib, json, os, sys, time
 import numpy as np
@@ -19,6 +20,10 @@ while time.time() < t_end:
     h.set_option("kernel", int(rng.choice([0, 1, 5])))
     h.set_option("chunk_bytes", int(rng.choice([1 << 20, 4 << 20, 64 << 20])))
     h.set_option("chunk_object_multiple", int(rng.choice([0, 64, 8192])))
+    h.set_option("sched_waves", int(rng.choice([0, 1, 2])))            # software-scheduled launch of binned chunks
+    h.set_option("sched_min_groups", int(rng.choice([1, 16, 4096])))
+    h.set_option("sched_share_below", int(rng.choice([0, 128, 1 << 20])))
+    h.set_option("pack_threads", int(rng.choice([3, 8, 16])))
     mode = int(rng.integers(0, 3))
     if mode == 0:
         h.set_option("host_auto", 1)
@@ -53,5 +58,21 @@ while time.time() < t_end:
             print(json.dumps({"mismatch": True, "batch": batches, "object": int(i), "len": len(b), "raw": raw, "n": n}))
             sys.exit(1)
     batches += 1; objects += n; nbytes += int(lens.sum())
+    if batches % 7 == 0:                                   # a device-resident batch: plain launch against the static-scratch launch
+        m = int(rng.choice([1, 65, 3000, 200000]))
+        dl = np.minimum(np.exp(rng.normal(np.log(900.0), 1.7, m)), 150000).astype(np.uint64)
+        b = h.synth_arena("blob", 1234 + batches, 0, m, 0, lens=dl)
+        h.set_option("sched_waves", 0)
+        want = h.hash_device(b).copy()
+        h.set_option("sched_waves", int(rng.choice([0, 1, 2])))
+        if not (h.hash_device_static(b) == want).all() or h.device_status(0) != 0:
+            print(json.dumps({"mismatch": True, "batch": batches, "static_entry": True, "n": m}))
+            sys.exit(1)
+        j = int(rng.integers(0, m))
+        data = vit_amd.synth_bytes(1234 + batches, j, int(dl[j]))
+        if want[j].tobytes() != hashlib.sha1(b"blob %d\0" % len(data) + data).digest():
+            print(json.dumps({"mismatch": True, "batch": batches, "device_resident": True, "n": m, "object": j}))
+            sys.exit(1)
+        del b
 print(json.dumps({"seconds": seconds, "seed": seed, "batches": batches, "objects": objects, "GB": round(nbytes / 1e9, 2),
                   "mismatches": 0}))

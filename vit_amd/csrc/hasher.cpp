@@ -29,6 +29,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -635,8 +636,11 @@ int vit_hasher_create(const int* device_ids, int n_devices, vit_hasher** out)
     if (!h) return fail(nullptr, VIT_ERR_NOMEM, "out of host memory");
     try {
         h->queues.resize(ids.size());
+        // Thread budget: the machine's cores, at most 16 per device queue (what one
+        // PCIe link's worth of packing can use); option "pack_threads" overrides.
         unsigned hw = std::thread::hardware_concurrency();
-        h->pack_threads = int(hw ? (hw > 16 ? 16 : hw) : 4);
+        unsigned budget = std::min<unsigned>(hw ? hw : 4, 16u * unsigned(ids.size()));
+        h->pack_threads = int(std::max(1u, budget));
         h->pool.reset(new vit::WorkPool(pool_threads_for(h)));
     } catch (const std::exception&) {
         delete h;
