@@ -362,12 +362,13 @@ __global__ __launch_bounds__(64 * WPB, BPS == 4 ? 2 : (BPS == 1 ? 4 : 5)) void s
 //     the hardware cannot leave two long groups on one SIMD; measured, they do
 //     not pay for themselves as helpers (two waves per SIMD: 5.76 ms against
 //     5.60 ms for leaders alone), so the default launches none.
-// What bounds the leaders-only launch is the rate of ONE wave on a SIMD: a lone
-// wave issues an instruction every 4.8 cycles (1.32 us per block), not every
-// 4.0 as five waves together do; a second stage of DMA in flight for such
-// waves was tried and changed nothing, the stalls are between dependent vector
-// instructions, not memory.  A 4097-block group cannot run on two waves (one
-// SHA-1 stream per lane), so 4097 x 1.32 us = 5.4 ms is this batch's floor.
+// What bounds the leaders-only launch is the rate of ONE wave on a SIMD: 1.32 us
+// per block against 1.10 for five waves sharing it (the arithmetic alone runs
+// at about 1.2 us per block on a lone wave; its LDS reads and DMA issue, which
+// other waves would cover, add the rest).  A second stage of DMA in flight for
+// such waves was tried and changed nothing: the next stage's data already lands
+// in time.  A 4097-block group cannot run on two waves (one SHA-1 stream per
+// lane), so 4097 x 1.32 us = 5.4 ms is this batch's floor.
 // Every wave leaves once the cursor has passed the last group, which every wave
 // observes.  The state returns to all-zero at the end of the launch (each wave
 // unregisters, each leader withdraws its length, the last wave out clears the
