@@ -674,12 +674,6 @@ int vit_hasher_create(const int* device_ids, int n_devices, vit_hasher** out)
         if (r == hipSuccess) r = hipStreamSynchronize(q.stream[0]);
         if (r == hipSuccess) r = hipEventCreate(&q.ev_a);
         if (r == hipSuccess) r = hipEventCreate(&q.ev_b);
-        // Timing events are made here so that a timed run creates none.
-        for (int i = 0; i < 129 && r == hipSuccess; ++i) {
-            hipEvent_t e = nullptr;
-            r = hipEventCreate(&e);
-            if (r == hipSuccess) q.timing.push_back(e);
-        }
         for (Staging& s : q.st)
             if (r == hipSuccess) r = hipEventCreateWithFlags(&s.done, hipEventDisableTiming);
         if (r != hipSuccess) {
@@ -1230,19 +1224,22 @@ int vit_time_hash_device(vit_hasher* h, int dev, const void* d_arena, uint64_t a
     Queue* q = queue_of(h, dev);
     if (!q || iters < 0 || warmup < 0 || (iters && !ms_each)) return h ? fail(h, VIT_ERR_ARG, "bad arguments") : VIT_ERR_ARG;
     HIP_TRY(h, hipSetDevice(q->device));
+    VIT_NOEXCEPT_BEGIN
+    // Timing events are made by the first call, warm-up calls (iters == 0) included, and kept:
+    // a timed run that was preceded by a warm-up call creates none.  (Not at vit_hasher_create:
+    // a hundred events cost milliseconds that a process hashing one small tree would pay for nothing.)
+    std::vector<hipEvent_t>& ev = q->timing;
+    while (ev.size() < std::max<size_t>(size_t(iters) + 1, 257)) {
+        hipEvent_t e = nullptr;
+        HIP_TRY(h, hipEventCreate(&e));
+        ev.push_back(e);
+    }
     for (int i = 0; i < warmup; ++i)
         if (int rc = vit_hash_arena_device(h, dev, d_arena, arena_bytes, d_offsets, d_nblocks, d_order, n, d_digests, nullptr)) return rc;
     HIP_TRY(h, hipStreamSynchronize(q->stream[0]));
     if (iters == 0) return VIT_OK;
     // The launches are queued back to back with an event between each two and the
     // host waits once, at the end: no host round trip separates the kernels.
-    VIT_NOEXCEPT_BEGIN
-    std::vector<hipEvent_t>& ev = q->timing;
-    while (ev.size() < size_t(iters) + 1) {
-        hipEvent_t e = nullptr;
-        HIP_TRY(h, hipEventCreate(&e));
-        ev.push_back(e);
-    }
     HIP_TRY(h, hipEventRecord(ev[0], q->stream[0]));
     for (int i = 0; i < iters; ++i) {
         if (int rc = vit_hash_arena_device(h, dev, d_arena, arena_bytes, d_offsets, d_nblocks, d_order, n, d_digests, nullptr)) return rc;
