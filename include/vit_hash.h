@@ -209,6 +209,20 @@ int vit_bin_order_device(vit_hasher *h, int dev, const uint32_t *d_nblocks, uint
  * reference is single-threaded and has no counterpart (src/commit.cpp:143). */
 int vit_shard_plan(const uint32_t *nblocks, uint64_t n, int n_queues, uint32_t *queue_of);
 
+/* The balance "host_auto" strikes, as a plan: on_host[i] = 1 if object i (content
+ * length len[i]) would be hashed on host threads beside the GPU batch, given
+ * bytes-per-second rates of one GPU lane, one host core hashing, one pinned
+ * host-to-device copy and one host core packing, the number of device queues and
+ * the host thread budget.  Objects under 64 KiB never move; from the longest
+ * down, objects move while the host side (hashing what moved plus packing what
+ * stayed, over the threads) would still finish before the GPU side (its bytes
+ * through 0.8 x copy rate per queue, never less than its longest object on one
+ * lane); a run of equal lengths may be split.  Host-only; needs no device.  The
+ * reference hashes every object on its one thread (src/commit.cpp:93-94). */
+int vit_host_split_plan(const uint64_t *len, uint64_t n, uint64_t lane_rate, uint64_t core_rate,
+                        uint64_t copy_rate, uint64_t pack_rate, int n_queues, int threads,
+                        uint8_t *on_host);
+
 /* Launch shape of the SHA-1 kernel for n objects (n <= 2^32 - 1): workgroups
  * and threads per workgroup.  Host-only; lets the launch arithmetic be checked
  * at sizes no test can allocate. */

@@ -157,6 +157,62 @@ def test_shard_plan_balances_bytes_not_counts(lib):
     assert (np.diff(plan.astype(np.int64)) >= 0).all()
 
 
+RATES = dict(lane=47e6, core=2.5e9, copy=56e9, pack=9e9)      # what one MI355X box measured
+
+
+def split(lib, lens, queues=1, threads=16, **over):
+    r = dict(RATES, **over)
+    lens = np.ascontiguousarray(lens, dtype=np.uint64)
+    out = np.zeros(max(len(lens), 1), dtype=np.uint8)
+    rc = lib.vit_host_split_plan(lens.ctypes.data, len(lens), int(r["lane"]), int(r["core"]), int(r["copy"]), int(r["pack"]),
+                                 queues, threads, out.ctypes.data)
+    assert rc == 0
+    return out[:len(lens)].astype(bool)
+
+
+def test_host_split_plan_balances_the_two_sides(lib):
+    """The policy behind host_auto, as a pure function of lengths and rates (no device needed)."""
+    rng = np.random.default_rng(11)
+    # small objects never move, whatever the rates
+    assert not split(lib, rng.integers(0, 65536, 5000)).any()
+    assert not split(lib, []).any()
+    # config 5: four 2 GiB giants among a million tiny objects -> exactly the giants
+    lens = np.concatenate([np.full(4, 2 << 30), rng.integers(0, 257, 100000)]).astype(np.uint64)
+    on = split(lib, lens)
+    assert on[:4].all() and not on[4:].any()
+    # one object beyond 4 GiB among small ones: a lane would need 90 s
+    on = split(lib, [6, (1 << 32) + 5, 0])
+    assert on.tolist() == [False, True, False]
+    # a uniform batch of large objects is SHARED, not dumped on the host: equal lengths are split by index
+    lens = np.full(3000, 256 << 10, dtype=np.uint64)
+    on = split(lib, lens)
+    k = int(on.sum())
+    assert 0 < k < 3000 and on[:k].all() and not on[k:].any()
+    # the host takes more when its cores are faster, the GPU keeps more when its lanes are
+    assert split(lib, lens, core=1.25e9).sum() < k < split(lib, lens, core=5e9).sum()
+    assert split(lib, lens, lane=94e6).sum() <= k
+    # more queues drain the GPU side faster: fewer objects move; more threads: more do
+    assert split(lib, lens, queues=4, threads=16).sum() < k
+    assert split(lib, lens, threads=4).sum() < k < split(lib, lens, threads=64).sum()
+    # skewed (config 4): what moves is a prefix of the (length, index) order: nothing shorter than a moved object stays
+    sizes = np.exp(rng.normal(np.log(4500.0), 1.55, 200000))
+    sizes = np.minimum(sizes * (15000.0 / sizes.mean()), 32 << 20).astype(np.uint64)
+    on = split(lib, sizes)
+    assert 0 < on.sum() < 0.1 * len(sizes)
+    assert sizes[on].min() >= 65536 and sizes[on].min() >= sizes[~on].max()
+    moved_bytes, all_bytes = float(sizes[on].sum()), float(sizes.sum())
+    assert 0.2 < moved_bytes / all_bytes < 0.7                       # both sides carry a real share of the bytes
+    # the model behind it: neither side is left far behind the other
+    gpu_t = max((all_bytes - moved_bytes) / min(0.8 * RATES["copy"], RATES["pack"] * 16), float(sizes[~on].max()) / RATES["lane"])
+    host_t = (moved_bytes / RATES["core"] + (all_bytes - moved_bytes) / RATES["pack"]) / 16
+    assert 0.7 < host_t / gpu_t < 1.3, (host_t, gpu_t)
+    # bad arguments
+    one = np.zeros(1, dtype=np.uint8)
+    assert lib.vit_host_split_plan(lens.ctypes.data, 1, 0, 1, 1, 1, 1, 1, one.ctypes.data) == -1
+    assert lib.vit_host_split_plan(lens.ctypes.data, 1, 1, 1, 1, 1, 0, 1, one.ctypes.data) == -1
+    assert lib.vit_host_split_plan(None, 1, 1, 1, 1, 1, 1, 1, one.ctypes.data) == -1
+
+
 def test_launch_shape_does_not_wrap_at_the_top_of_the_object_range(lib):
     """The ABI admits n up to 2^32 - 1; the launch arithmetic must cover every object there
     (n + 63 and n + 255 wrap in 32 bits for the last values of n)."""

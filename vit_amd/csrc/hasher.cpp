@@ -797,52 +797,21 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
     VIT_NOEXCEPT_BEGIN
     for (Queue& q : h->queues) { drain(q); q.status_seen = 0; }
 
-    // Which objects leave the GPU.  One SHA-1 stream is serial: a lane sustains
-    // about 45 MB/s and a host core with SHA extensions about 2 GB/s, while a
-    // whole batch moves through pack + PCIe at about 40 GB/s per GPU.  The auto
-    // policy balances the two sides with rates measured on this machine
-    // (calibrate): starting from the longest object, an object of 64 KiB or more
-    // moves to the host threads as long as the host side still finishes before
-    // the GPU side would with the object on it.
-    //   GPU side:  its bytes through the queues (0.8 x the copy rate each, the
-    //              pipeline's measured efficiency, and no faster than the
-    //              threads can pack), never less than its longest object on one
-    //              lane;
-    //   host side: the thread-seconds of hashing the moved bytes AND of packing
-    //              the GPU side's bytes, over the thread budget (one pool carries
-    //              both), never less than the longest moved object on one core.
-    // Objects move one by one in (length, index) order, so a run of equal
-    // lengths may be split between the two sides.
+    // Which objects leave the GPU for host threads: a fixed threshold, or (auto)
+    // the balance vit::plan_host_split strikes with the rates measured on this
+    // machine (calibrate), see packer.h.
     std::vector<uint32_t> nb(n);
     std::vector<uint64_t> gpu_idx, host_idx;
     uint64_t threshold = 0;
     if (h->host_policy == 2) threshold = h->host_threshold;
     else if (h->host_policy == 1) {
-        uint64_t total = 0;
-        std::vector<uint64_t> cand;
-        for (uint64_t i = 0; i < n; ++i) {
-            total += len[i];
-            if (len[i] >= (64u << 10)) cand.push_back(i);
-        }
-        if (!cand.empty()) {
+        bool any = false;
+        for (uint64_t i = 0; i < n && !any; ++i) any = len[i] >= vit::kHostSplitMin;
+        if (any) {
             if (int rc = calibrate(h)) return rc;
-            std::stable_sort(cand.begin(), cand.end(), [&](uint64_t a, uint64_t b) { return len[a] > len[b]; });
-            const double threads = double(h->pack_threads);
-            const double queue_rate = std::min(0.8 * h->copy_rate * double(h->queues.size()), h->pack_rate * threads);
-            const double longest = double(len[cand[0]]);
-            double gpu_bytes = double(total), host_bytes = 0;
-            size_t moved = 0;
-            for (uint64_t i : cand) {
-                const double L = double(len[i]);
-                const double gpu_time = std::max(gpu_bytes / queue_rate, L / h->lane_rate);
-                const double host_time = std::max(((host_bytes + L) / h->core_rate + (gpu_bytes - L) / h->pack_rate) / threads,
-                                                  longest / h->core_rate);
-                if (host_time >= gpu_time) break;
-                gpu_bytes -= L; host_bytes += L;
-                ++moved;
-            }
-            host_idx.assign(cand.begin(), cand.begin() + long(moved));
-            if (moved) threshold = len[cand[moved - 1]] - 1;
+            vit::plan_host_split(len, n, vit::SplitRates{h->lane_rate, h->core_rate, h->copy_rate, h->pack_rate},
+                                 int(h->queues.size()), h->pack_threads, host_idx);
+            if (!host_idx.empty()) threshold = len[host_idx.back()] - 1;
         }
     }
     h->last_host_threshold = threshold;

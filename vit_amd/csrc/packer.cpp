@@ -14,6 +14,7 @@
 #include "host_util.h"
 #include "packer.h"
 
+#include <algorithm>
 #include <cstring>
 #include <immintrin.h>
 #include <numeric>
@@ -130,6 +131,35 @@ bool bin_order(const uint32_t* nblocks, uint64_t n, uint32_t* order)
     return true;
 }
 
+void plan_host_split(const uint64_t* len, uint64_t n, const SplitRates& r, int queues, int threads,
+                     std::vector<uint64_t>& out)
+{
+    out.clear();
+    if (!(r.lane > 0) || !(r.core > 0) || !(r.copy > 0) || !(r.pack > 0) || queues < 1 || threads < 1) return;
+    uint64_t total = 0;
+    std::vector<uint64_t> cand;
+    for (uint64_t i = 0; i < n; ++i) {
+        total += len[i];
+        if (len[i] >= kHostSplitMin) cand.push_back(i);
+    }
+    if (cand.empty()) return;
+    std::stable_sort(cand.begin(), cand.end(), [&](uint64_t a, uint64_t b) { return len[a] > len[b]; });
+    const double nt = double(threads);
+    const double queue_rate = std::min(0.8 * r.copy * double(queues), r.pack * nt);
+    const double longest = double(len[cand[0]]);
+    double gpu_bytes = double(total), host_bytes = 0;
+    size_t moved = 0;
+    for (uint64_t i : cand) {
+        const double L = double(len[i]);
+        const double gpu_time = std::max(gpu_bytes / queue_rate, L / r.lane);
+        const double host_time = std::max(((host_bytes + L) / r.core + (gpu_bytes - L) / r.pack) / nt, longest / r.core);
+        if (host_time >= gpu_time) break;
+        gpu_bytes -= L; host_bytes += L;
+        ++moved;
+    }
+    out.assign(cand.begin(), cand.begin() + long(moved));
+}
+
 static inline uint64_t mix64(uint64_t z)
 {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -210,6 +240,21 @@ int vit_bin_order(const uint32_t* nblocks, uint64_t n, uint32_t* order)
     if (n > 0xFFFFFFFFull) return VIT_ERR_RANGE;
     try { return vit::bin_order(nblocks, n, order) ? 1 : 0; }
     catch (const std::exception&) { return VIT_ERR_NOMEM; }
+}
+
+int vit_host_split_plan(const uint64_t* len, uint64_t n, uint64_t lane_rate, uint64_t core_rate, uint64_t copy_rate,
+                        uint64_t pack_rate, int n_queues, int threads, uint8_t* on_host)
+{
+    if (n && (!len || !on_host)) return VIT_ERR_ARG;
+    if (!lane_rate || !core_rate || !copy_rate || !pack_rate || n_queues < 1 || threads < 1) return VIT_ERR_ARG;
+    try {
+        std::vector<uint64_t> moved;
+        vit::plan_host_split(len, n, vit::SplitRates{double(lane_rate), double(core_rate), double(copy_rate), double(pack_rate)},
+                             n_queues, threads, moved);
+        std::memset(on_host, 0, size_t(n));
+        for (uint64_t i : moved) on_host[i] = 1;
+        return VIT_OK;
+    } catch (const std::exception&) { return VIT_ERR_NOMEM; }
 }
 
 void vit_synth_bytes(uint64_t seed, uint64_t index, uint8_t* dst, uint64_t len)

@@ -1,6 +1,7 @@
 // packer.h — host-side arena packing primitives (see packer.cpp).
 #pragma once
 #include <cstdint>
+#include <vector>
 
 namespace vit {
 
@@ -17,5 +18,24 @@ void pack_one(const char* type, uint32_t type_len, const uint8_t* data, uint64_t
 void pack_fence();
 // order[] = indices by block count, longest first, stable; false if all equal.
 bool bin_order(const uint32_t* nblocks, uint64_t n, uint32_t* order);
+
+// Which objects of a batch leave the GPU for host threads.  One SHA-1 stream is
+// serial: a GPU lane sustains `lane` bytes/s and a host core `core`, while a
+// whole batch moves through pack + PCIe at 0.8 x `copy` per queue (the pipeline's
+// measured efficiency) and no faster than `threads` cores pack at `pack` each.
+// Starting from the longest object, an object of kHostSplitMin bytes or more
+// moves to the host threads as long as the host side would still finish before
+// the GPU side would with the object on it:
+//   GPU side:  its bytes through the queues, never less than its longest object
+//              on one lane;
+//   host side: the thread-seconds of hashing the moved bytes AND of packing the
+//              GPU side's bytes, over the thread budget (one pool carries both),
+//              never less than the longest moved object on one core.
+// Objects move one by one in (length, index) order, so a run of equal lengths
+// may be split between the two sides.  out: the moved indices, longest first.
+struct SplitRates { double lane, core, copy, pack; };
+constexpr uint64_t kHostSplitMin = 64u << 10;
+void plan_host_split(const uint64_t* len, uint64_t n, const SplitRates& r, int queues, int threads,
+                     std::vector<uint64_t>& out);
 
 }  // namespace vit
