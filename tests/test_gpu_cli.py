@@ -255,3 +255,26 @@ def test_write_tree_flags_no_store_and_rewrite(golden_trees, worktrees, tmp_path
     assert p.stdout.decode() == rec["root"] + "\n" and "already-stored 0" in p.stderr.decode()
     assert os.stat(some).st_ino != first                  # a new file was renamed into place
     assert stored_objects(wt) == objs
+
+
+def test_other_deflate_levels_store_the_same_objects(golden_trees, worktrees, tmp_path):
+    """--deflate-level: files differ from the reference's in their bytes, not in what they hold: same ids, every
+    stored object inflates to "<type> <len>\\0" + content (stored_objects checks name == SHA-1 of that), git reads them."""
+    name = "c1_1000x4096"
+    rec = golden_trees[name]
+    ref = fresh_copy(worktrees[name], tmp_path / "ref")
+    assert vit(ref, "write-tree").stdout.decode().strip() == rec["root"]
+    want = stored_objects(ref)
+    sizes = {}
+    for level in (0, 1, 9):
+        wt = fresh_copy(worktrees[name], tmp_path / ("l%d" % level))
+        assert vit(wt, "write-tree", "--deflate-level=%d" % level).stdout.decode().strip() == rec["root"]
+        got = stored_objects(wt)
+        assert got == want
+        base = os.path.join(wt, ".git", "objects")
+        sizes[level] = sum(os.path.getsize(os.path.join(base, d, f)) for d in os.listdir(base) for f in os.listdir(os.path.join(base, d)))
+        if shutil.which("git"):
+            blob = rec["blob_ids"][0]
+            out = subprocess.run(["git", "--git-dir", os.path.join(wt, ".git"), "cat-file", "-t", blob], capture_output=True, text=True)
+            assert out.stdout.strip() == "blob", out.stderr
+    assert sizes[0] >= sizes[1] >= sizes[9] * 0.99

@@ -108,6 +108,8 @@ def main():
     ap.add_argument("--git", action="store_true", help="also run real `git add -A && git write-tree` on the worktree")
     ap.add_argument("--dir", default=None, help="where to build the worktree (default: a temp dir, /dev/shm if present)")
     ap.add_argument("--skip-reference", action="store_true")
+    ap.add_argument("--levels", type=int, nargs="*", default=[],
+                    help="also run `vit write-tree --deflate-level=N` for these zlib levels (same ids, other stored bytes)")
     a = ap.parse_args()
     base = a.dir or tempfile.mkdtemp(prefix="vitwt_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     wt = os.path.join(base, "wt")
@@ -163,6 +165,12 @@ def main():
                                  "objects_per_s": round((nb + nt) / dt, 1),
                                  "ids_only_wall_s": round(dt2, 3), "ids_only_stats": stats2}
         out["match"] = bool(root == want.hex() == root2)
+        for level in a.levels:
+            shutil.rmtree(os.path.join(wt, ".git"), ignore_errors=True)
+            r3, dt3, st3 = run_vit(wt, ["--deflate-level=%d" % level])
+            out["gpu_write_tree_level_%d" % level] = {"root": r3, "wall_s": round(dt3, 3), "stats": st3,
+                                                      "objects_per_s": round((nb + nt) / dt3, 1)}
+            out["match"] = out["match"] and r3 == root
         if a.git and shutil.which("git"):
             say("git add -A && git write-tree ...")
             shutil.rmtree(os.path.join(wt, ".git"), ignore_errors=True)

@@ -82,17 +82,20 @@ int hexNibble(char c)
 // the ones compress() gives (tests compare them).
 class Deflater {
 public:
-    Deflater()
-    {
-        std::memset(&zs_, 0, sizeof zs_);
-        ok_ = deflateInit(&zs_, Z_DEFAULT_COMPRESSION) == Z_OK;
-    }
+    Deflater() { std::memset(&zs_, 0, sizeof zs_); }
     ~Deflater() { if (ok_) deflateEnd(&zs_); }
     Deflater(const Deflater&) = delete;
     Deflater& operator=(const Deflater&) = delete;
 
-    bool run(const std::string& type, const std::string& content, std::string& out)
+    // level: zlib's 0..9, or Z_DEFAULT_COMPRESSION (-1), which is what compress() uses
+    bool run(int level, const std::string& type, const std::string& content, std::string& out)
     {
+        if (!ok_ || level != level_) {
+            if (ok_) deflateEnd(&zs_);
+            std::memset(&zs_, 0, sizeof zs_);
+            ok_ = deflateInit(&zs_, level) == Z_OK;
+            level_ = level;
+        }
         if (!ok_ || deflateReset(&zs_) != Z_OK) return false;
         std::string header = type;
         header += ' ';
@@ -124,12 +127,13 @@ public:
 private:
     z_stream zs_;
     bool ok_ = false;
+    int level_ = 0;
 };
 
-bool deflateFramed(const std::string& type, const std::string& content, std::string& out)
+bool deflateFramed(int level, const std::string& type, const std::string& content, std::string& out)
 {
     static thread_local Deflater deflater;
-    return deflater.run(type, content, out);
+    return deflater.run(level, type, content, out);
 }
 
 // Write atomically: a reader (or a crash) never sees a half-written object.
@@ -304,6 +308,7 @@ ObjectStore::ObjectStore(std::string objects_dir, std::vector<int> devices)
 {
     unsigned hw = std::thread::hardware_concurrency();
     io_threads_ = int(hw ? std::min(hw, 16u) : 4);
+    if (const char* e = std::getenv("VIT_DEFLATE_LEVEL")) setDeflateLevel(std::atoi(e));
 }
 
 ObjectStore::~ObjectStore()
@@ -391,13 +396,14 @@ WorkPool::Ticket ObjectStore::storeAsync(const std::string& type, const std::vec
     const size_t slices = std::min(n, size_t(io_threads_) * 8);
     const std::string* c = contents.data();
     const uint8_t* r = raw.data();
-    return pool().submit(WorkPool::LOW, slices, [this, type, c, r, n, slices, &outcome](size_t s) {
+    const int level = deflate_level_;
+    return pool().submit(WorkPool::LOW, slices, [this, type, c, r, n, slices, level, &outcome](size_t s) {
         for (size_t i = n * s / slices; i < n * (s + 1) / slices; ++i) {
             try {
                 const std::string path = objectPath(toHex(r + i * 20, 20));
                 if (skip_existing_ && alreadyStored(path)) { ++outcome.skipped; continue; }
                 std::string z;
-                if (!deflateFramed(type, c[i], z)) { outcome.failed = 1; continue; }
+                if (!deflateFramed(level, type, c[i], z)) { outcome.failed = 1; continue; }
                 if (!writeFileAtomic(path, z)) outcome.failed = 2;
             } catch (const std::exception&) { outcome.failed = 2; }      // out of memory in deflate or the path strings
         }

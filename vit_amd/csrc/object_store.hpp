@@ -84,6 +84,11 @@ public:
     // executables get mode 100755, symlinks are stored as 120000 blobs holding the link target, other special
     // files are ignored; the id is then what `git add -A && git write-tree` gives on a worktree without ignore rules.
     void setGitTreeRules(bool on) { git_rules_ = on; }
+    // zlib level of the stored objects.  -1 (default) = what the reference's compress() uses (src/commit.cpp:100): the
+    // stored files are then byte for byte the reference's.  0..9: any other level gives files that differ from the
+    // reference's in their bytes but hold the same object (they inflate to the same "<type> <len>\0" + content, so the
+    // reference's readObject and git read them); level 1 deflates about three times faster, level 0 stores.
+    void setDeflateLevel(int level) { deflate_level_ = level < -1 ? -1 : (level > 9 ? 9 : level); }
     void setIoThreads(int n) { io_threads_ = n < 1 ? 1 : n; }
     void setBatchBytes(uint64_t b) { batch_bytes_ = b < 1 ? 1 : b; }
     const StoreStats& lastStats() const { return stats_; }
@@ -106,6 +111,7 @@ private:
     bool store_ = true;
     bool skip_existing_ = true;
     bool git_rules_ = false;
+    int deflate_level_ = -1;
     int io_threads_ = 8;
     // Blobs per hashing batch, by bytes.  128 MiB: a dozen or more batches on a worktree of gigabytes, so that
     // reading, hashing and storing overlap, and three batches of contents in memory at most.

@@ -3,8 +3,9 @@
 //
 //   vit init
 //   vit hash-object -w <file>            reference src/main.cpp:90-120
-//   vit write-tree [--stats] [--no-store] [--rewrite] [--git-order]    reference src/main.cpp:155-163
-//                                        (--git-order: Git's tree rules where the reference's differ)
+//   vit write-tree [--stats] [--no-store] [--rewrite] [--git-order] [--deflate-level=N]    reference src/main.cpp:155-163
+//                                        (--git-order: Git's tree rules where the reference's differ;
+//                                         --deflate-level: zlib level of the stored objects, default the reference's)
 //   vit commit-tree <tree> -p <parent> -m <message>   reference src/main.cpp:165-186
 //   vit cat-file -p <hash>               reference src/main.cpp:68-88
 //   vit ls-tree <hash> --name-only|-l    reference src/main.cpp:122-153
@@ -76,6 +77,7 @@ bool cmdWriteTree(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--no-store")) vit::defaultStore().setStoreObjects(false);
         else if (!std::strcmp(argv[i], "--rewrite")) vit::defaultStore().setSkipExisting(false);
         else if (!std::strcmp(argv[i], "--git-order")) vit::defaultStore().setGitTreeRules(true);
+        else if (!std::strncmp(argv[i], "--deflate-level=", 16)) vit::defaultStore().setDeflateLevel(std::atoi(argv[i] + 16));
         else { std::cerr << "Unknown flag: " << argv[i] << '\n'; return false; }
     }
     const std::string id = writeTree(".");
