@@ -543,13 +543,17 @@ int read_status_word(vit_hasher* h, Queue& q, uint32_t* out)
 // Measure, once per hasher and on its first queue, the four rates the auto
 // policy balances with (anything set through an option stays as set):
 //   core_rate  one host thread's SHA-1 (vit::host_object_id over 4 MiB)
-//   pack_rate  one host thread packing into a pinned staging arena (4 MiB)
+//   pack_rate  one host thread packing into a pinned staging arena: up to 8 MiB of
+//              the batch's own longest object when that is 1 MiB or more (data
+//              as cold in the caches as the batch will be), else a 4 MiB buffer
+//              of the library's (cache-warm, optimistic); real batches of 256 MiB
+//              and more then correct the rate (hash_batch)
 //   copy_rate  one pinned host-to-device copy (32 MiB)
 //   lane_rate  one GPU lane: a lone wave running 1024 compressions back to back,
 //              times 0.8: with four other waves resident, the SIMD's oldest wave
 //              (a long object's wave always is) gets about that share of issue
 //              (1.15 us per block alone, 1.4 to 1.5 us in a full launch).
-int calibrate(vit_hasher* h)
+int calibrate(vit_hasher* h, const uint8_t* sample, uint64_t sample_len)
 {
     if (h->calibrated) return VIT_OK;
     const auto t0 = clk::now();
@@ -571,11 +575,14 @@ int calibrate(vit_hasher* h)
         Staging& s = q.st[0];
         if (ensure_arena(q, s, kCopy) != VIT_OK) return fail(h, VIT_ERR_NOMEM, "calibration: %s", q.err.c_str());
         if (!h->pack_fixed) {
-            const uint64_t len = kHost - 64, nb = (4 + 1 + 7 + 1 + len + 9 + 63) / 64;
+            const bool own = sample && sample_len >= (1u << 20);
+            const uint8_t* from = own ? sample : src.data();
+            const uint64_t len = own ? std::min<uint64_t>(sample_len, 8ull << 20) : kHost - 64;
+            const uint64_t nb = (4 + 1 + vit::decimal_digits(len) + 1 + len + 9 + 63) / 64;
             double best = 1e30;
-            for (int r = 0; r < 2; ++r) {
+            for (int r = 0; r < (own ? 1 : 2); ++r) {     // the caller's data is cold exactly once
                 const auto t = clk::now();
-                vit::pack_one("blob", 4, src.data(), len, s.h_arena, nb);
+                vit::pack_one("blob", 4, from, len, s.h_arena, nb);
                 vit::pack_fence();
                 best = std::min(best, double(ns_since(t)) * 1e-9);
             }
@@ -808,7 +815,9 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
         bool any = false;
         for (uint64_t i = 0; i < n && !any; ++i) any = len[i] >= vit::kHostSplitMin;
         if (any) {
-            if (int rc = calibrate(h)) return rc;
+            uint64_t longest = 0;
+            for (uint64_t i = 1; i < n; ++i) if (len[i] > len[longest]) longest = i;
+            if (int rc = calibrate(h, data[longest], len[longest])) return rc;
             vit::plan_host_split(len, n, vit::SplitRates{h->lane_rate, h->core_rate, h->copy_rate, h->pack_rate},
                                  int(h->queues.size()), h->pack_threads, host_idx);
             if (!host_idx.empty()) threshold = len[host_idx.back()] - 1;
