@@ -87,7 +87,7 @@ bool cmdWriteTree(int argc, char** argv)
         const vit::StoreStats& s = vit::defaultStore().lastStats();
         std::cerr << "blobs " << s.blobs << " trees " << s.trees << " bytes " << s.bytes << " already-stored " << s.skipped
                   << " | walk " << s.walk_s
-                  << " s read " << s.read_s << " s hash " << s.hash_s << " s hash+deflate+store " << s.deflate_store_s
+                  << " s read-wait " << s.read_s << " s hash " << s.hash_s << " s blobs-pipeline(read|hash|deflate+store) " << s.deflate_store_s
                   << " s total " << s.total_s << " s\n";
     }
     return true;
