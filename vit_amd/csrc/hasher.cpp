@@ -427,21 +427,30 @@ int run_queue_body(Queue& q, const Job& job, const std::vector<uint64_t>& mine, 
     q.trace_log.clear();
     q.chunks_this_call = 0;
     if (h->trace) HIP_TRYQ(q, hipEventRecord(q.ev_a, q.stream[0]));
-    std::vector<uint64_t> longs, rest;
-    for (uint64_t i : mine) (job.nb[i] >= kLongBlocks ? longs : rest).push_back(i);
-    std::stable_sort(longs.begin(), longs.end(), [&](uint64_t a, uint64_t b) { return job.nb[a] > job.nb[b]; });
+    // One pass over the queue's objects: which are long, and what the rest add up to.
+    // Without long objects (the common case) the rest IS the list as given: no copy.
+    std::vector<uint64_t> longs, rest_copy;
+    uint64_t rest_bytes = 0, rest_longest = 0;
+    for (uint64_t i : mine) {
+        const uint32_t b = job.nb[i];
+        if (b >= kLongBlocks) { longs.push_back(i); continue; }
+        rest_bytes += uint64_t(b) * 64;
+        rest_longest = std::max<uint64_t>(rest_longest, b);
+    }
+    if (!longs.empty()) {
+        rest_copy.reserve(mine.size() - longs.size());
+        for (uint64_t i : mine) if (job.nb[i] < kLongBlocks) rest_copy.push_back(i);
+        std::stable_sort(longs.begin(), longs.end(), [&](uint64_t a, uint64_t b) { return job.nb[a] > job.nb[b]; });
+    }
+    const std::vector<uint64_t>& rest = longs.empty() ? mine : rest_copy;
 
-    // Chunk boundaries: as many objects as fit the staging budget (at least one).
-    auto cut = [&](const std::vector<uint64_t>& v, uint64_t budget) {
-        std::vector<std::pair<size_t, size_t>> out;
-        for (size_t pos = 0; pos < v.size();) {
-            uint64_t blocks = 0;
-            size_t end = pos;
-            while (end < v.size() && (end == pos || (blocks + job.nb[v[end]]) * 64 <= budget)) blocks += job.nb[v[end++]];
-            out.emplace_back(pos, end);
-            pos = end;
-        }
-        return out;
+    // Chunk boundaries: as many objects from v[pos] on as fit the staging budget (at
+    // least one); returns the end.  Cut as the chunks are submitted, not up front.
+    auto cut_from = [&](const std::vector<uint64_t>& v, size_t pos, uint64_t budget) {
+        uint64_t blocks = 0;
+        size_t end = pos;
+        while (end < v.size() && (end == pos || (blocks + job.nb[v[end]]) * 64 <= budget)) blocks += job.nb[v[end++]];
+        return end;
     };
     // A chunk's kernel lasts at least as long as its longest object on one lane
     // (45 MB/s; 1.5 ms for 64 KiB), while its transfer runs about 1000 times
@@ -451,15 +460,9 @@ int run_queue_body(Queue& q, const Job& job, const std::vector<uint64_t>& mine, 
     // objects gave twice the throughput of 64 MiB on a skewed 15 GB batch.
     // Bounds: [configured chunk size, 1 GiB], and at most 1/8 of the batch so
     // that packing, copying and hashing still overlap.
-    uint64_t rest_bytes = 0, rest_longest = 0;
-    for (uint64_t i : rest) {
-        rest_bytes += uint64_t(job.nb[i]) * 64;
-        rest_longest = std::max<uint64_t>(rest_longest, job.nb[i]);
-    }
     uint64_t chunk = std::min<uint64_t>(rest_longest * 64 * h->chunk_object_multiple, rest_bytes / 8);
     chunk = std::min<uint64_t>(std::max<uint64_t>(chunk, h->chunk_bytes), 1ull << 30);
-    const auto long_chunks = cut(longs, std::max<uint64_t>(chunk, 256ull << 20));
-    const auto rest_chunks = cut(rest, chunk);
+    const uint64_t long_chunk = std::max<uint64_t>(chunk, 256ull << 20);
 
     // Long chunks go first and then whenever their staging set has drained, so
     // that their lane-bound kernels run beside the short objects' chunks and
@@ -467,18 +470,21 @@ int run_queue_body(Queue& q, const Job& job, const std::vector<uint64_t>& mine, 
     int rc;
     size_t next_long = 0;
     auto submit_long = [&]() -> int {
-        const auto& c = long_chunks[next_long++];
-        return submit_chunk(q, job, q.st[2], q.stream[2], longs.data() + c.first, c.second - c.first, pack_ns);
+        const size_t end = cut_from(longs, next_long, long_chunk);
+        const int r = submit_chunk(q, job, q.st[2], q.stream[2], longs.data() + next_long, end - next_long, pack_ns);
+        next_long = end;
+        return r;
     };
-    if (!long_chunks.empty() && (rc = submit_long())) return rc;
+    if (!longs.empty() && (rc = submit_long())) return rc;
     int turn = 0;
-    for (const auto& c : rest_chunks) {
-        if ((rc = submit_chunk(q, job, q.st[turn], q.stream[turn], rest.data() + c.first, c.second - c.first, pack_ns)))
-            return rc;
+    for (size_t pos = 0; pos < rest.size();) {
+        const size_t end = cut_from(rest, pos, chunk);
+        if ((rc = submit_chunk(q, job, q.st[turn], q.stream[turn], rest.data() + pos, end - pos, pack_ns))) return rc;
+        pos = end;
         turn ^= 1;
-        if (next_long < long_chunks.size() && hipEventQuery(q.st[2].done) == hipSuccess && (rc = submit_long())) return rc;
+        if (next_long < longs.size() && hipEventQuery(q.st[2].done) == hipSuccess && (rc = submit_long())) return rc;
     }
-    while (next_long < long_chunks.size())
+    while (next_long < longs.size())
         if ((rc = submit_long())) return rc;
     for (Staging& s : q.st)
         if ((rc = retire(q, s, job.digests))) return rc;
@@ -828,15 +834,34 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
     if (h->host_policy == 2 && threshold)
         for (uint64_t i = 0; i < n; ++i) if (len[i] > threshold) host_idx.push_back(i);
     for (uint64_t i : host_idx) { nb[i] = 0xFFFFFFFFu; host_bytes += len[i]; }      // marker: not for a lane
-    gpu_idx.reserve(n - host_idx.size());
-    for (uint64_t i = 0; i < n; ++i) {
-        if (len[i] && !data[i]) return fail(h, VIT_ERR_ARG, "object %llu: null data with non-zero length", (unsigned long long)i);
-        if (!host_idx.empty() && nb[i] == 0xFFFFFFFFu) { nb[i] = 0; continue; }
-        const uint64_t hl = tl ? tl + 1 + vit::decimal_digits(len[i]) + 1 : 0;
-        const uint64_t b = (hl + len[i] + 9 + 63) / 64;
-        if (b >= 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "object %llu too large for one lane", (unsigned long long)i);
-        nb[i] = uint32_t(b);
-        gpu_idx.push_back(i);
+    // Block counts and argument checks, on the pool for large batches (a million
+    // objects cost 3 ms on one thread, as much as two staging chunks take to copy).
+    {
+        std::atomic<uint64_t> bad_null{~0ull}, bad_long{~0ull};
+        const bool marked = !host_idx.empty();
+        auto count = [&](uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i) {
+                if (len[i] && !data[i]) { uint64_t cur = bad_null.load(); while (i < cur && !bad_null.compare_exchange_weak(cur, i)) {} continue; }
+                if (marked && nb[i] == 0xFFFFFFFFu) continue;                 // a host-lane object: keeps its marker
+                const uint64_t hl = tl ? tl + 1 + vit::decimal_digits(len[i]) + 1 : 0;
+                const uint64_t blocks = (hl + len[i] + 9 + 63) / 64;
+                if (blocks >= 0xFFFFFFFFull) { uint64_t cur = bad_long.load(); while (i < cur && !bad_long.compare_exchange_weak(cur, i)) {} continue; }
+                nb[i] = uint32_t(blocks);
+            }
+        };
+        const uint64_t slices = n >= 65536 ? std::min<uint64_t>(uint64_t(h->pack_threads) * 2, n / 16384) : 1;
+        if (slices <= 1) count(0, n);
+        else h->pool->run(vit::WorkPool::HIGH, size_t(slices), [&](size_t s) { count(n * s / slices, n * (s + 1) / slices); });
+        if (bad_null != ~0ull)
+            return fail(h, VIT_ERR_ARG, "object %llu: null data with non-zero length", (unsigned long long)bad_null.load());
+        if (bad_long != ~0ull)
+            return fail(h, VIT_ERR_RANGE, "object %llu too large for one lane", (unsigned long long)bad_long.load());
+    }
+    gpu_idx.resize(n - host_idx.size());
+    if (host_idx.empty()) for (uint64_t i = 0; i < n; ++i) gpu_idx[i] = i;
+    else {
+        uint64_t k = 0;
+        for (uint64_t i = 0; i < n; ++i) { if (nb[i] == 0xFFFFFFFFu) nb[i] = 0; else gpu_idx[k++] = i; }
     }
     h->last_host_objects = host_idx.size();
 
