@@ -97,6 +97,15 @@ int vit_hasher_device_count(const vit_hasher *h);
  *                         long object has its SIMD to itself (default 1; 2 adds a spare wave
  *                         per SIMD; 0 = always the hardware dispatcher)
  *  "sched_min_groups"     default 4096
+ *  "sched_tail_percent"   ... and only when the batch's longest object is at least this many
+ *                         percent of one SIMD's mean share of the work (arena bytes / 64 / 64
+ *                         lanes / SIMDs, in blocks): the scheduled launch trades about a
+ *                         quarter of the chip's rate for never letting a long object share its
+ *                         SIMD, which pays from about 0.78 of that mean on and costs batches of
+ *                         short objects a factor of three (default 75; 0 = whatever the lengths).
+ *                         Where the lengths exist in device memory only (vit_hash_arena_device
+ *                         with an order, vit_hash_arena_device_static) both launches are queued
+ *                         and their waves decide: those of the one not chosen leave at once
  *  "sched_share_below"    a spare wave works only while its SIMD's leader is on a group of at
  *                         most this many blocks (default 128)
  *  "debug_fail_at_chunk"  tests only: the N-th staged chunk of every later call fails

@@ -202,6 +202,7 @@ def test_software_scheduled_launch_gives_the_same_ids(hasher, waves):
     rng = np.random.default_rng(500 + waves)
     hasher.set_option("sched_waves", waves)
     hasher.set_option("sched_min_groups", 1)
+    hasher.set_option("sched_tail_percent", 0)
     for n in (1, 63, 65, 1000, 70_001, 400_000):
         lens = np.minimum(np.exp(rng.normal(np.log(1500.0), 1.5, n)), 300_000).astype(np.uint64)
         b = hasher.synth_arena("blob", 0x5EED0088, 0, n, 0, lens=lens)
@@ -233,6 +234,42 @@ def test_software_scheduled_launch_gives_the_same_ids(hasher, waves):
     assert (hasher.hash_blobs(blobs) == got).all()
     for i in (0, 7, len(lens) - 1):
         assert got[i].tobytes() == hashlib.sha1(b"blob %d\0" % lens[i] + blobs[i].tobytes()).digest()
+
+
+def test_scheduled_launch_is_chosen_by_the_tail(hasher):
+    """Default options, lengths known to the device only: the scheduled launch and the plain one are both
+    queued and their waves decide (longest object against a SIMD's mean share of the work).  Same ids either
+    way; a batch of short objects must not pay the scheduler's price (it ran 3.3 times slower under it), a
+    batch with a long tail must get its benefit."""
+    import statistics
+    import vit_amd
+    rng = np.random.default_rng(77)
+    cases = {"short": rng.integers(0, 257, 600_000).astype(np.uint64),
+             "tail": np.concatenate([rng.integers(0, 2000, 400_000), [3_000_000, 2_500_000]]).astype(np.uint64)}
+    for name, lens in cases.items():
+        n = len(lens)
+        b = hasher.synth_arena("blob", 0x5EED0090, 0, n, 0, lens=lens)
+        nb = b["nblocks"].download(np.uint32, 4 * n)
+        order_host, _ = vit_amd.bin_order(nb)
+        order = hasher.alloc(4 * n).upload(order_host)
+        hasher.set_option("sched_waves", 0)
+        want = hasher.hash_device(b, order=order).copy()
+        t_plain = statistics.median(hasher.time_hash_device(b, order=order, warmup=1, iters=5))
+        hasher.set_option("sched_waves", 1)
+        hasher.set_option("sched_tail_percent", 0)
+        t_forced = statistics.median(hasher.time_hash_device(b, order=order, warmup=1, iters=5))
+        hasher.set_option("sched_tail_percent", 75)
+        b["digests"].upload(np.zeros(20 * n, dtype=np.uint8))
+        assert (hasher.hash_device(b, order=order) == want).all(), name
+        t_auto = statistics.median(hasher.time_hash_device(b, order=order, warmup=1, iters=5))
+        b["digests"].upload(np.zeros(20 * n, dtype=np.uint8))
+        assert (hasher.hash_device_static(b) == want).all(), name
+        for i in (0, n - 1, int(np.argmax(lens))):
+            data = vit_amd.synth_bytes(0x5EED0090, i, int(lens[i]))
+            assert want[i].tobytes() == hashlib.sha1(b"blob %d\0" % len(data) + data).digest()
+        assert hasher.device_status() == 0
+        # the choice lands on the faster launch, give or take the cost of the launch that steps aside
+        assert t_auto < 1.25 * min(t_plain, t_forced) + 0.03, (name, t_plain, t_forced, t_auto)
 
 
 def test_plain_sha1_of_buffers(hasher, oracle, golden_objects):

@@ -56,6 +56,7 @@ def mixed(a):
     ms1 = h.time_hash_device(b, order=order, warmup=1, iters=a.iters)
     d1 = b["digests"].download(np.uint8, 20 * a.n).reshape(-1, 20).copy()
     out["scheduled"] = {}
+    h.set_option("sched_tail_percent", 0)                  # forced: the sweep measures the launch, not the library's choice
     for waves in a.sched_waves:                            # software-scheduled: resident waves pulling groups down the order
         for share in a.share_below:
             h.set_option("sched_waves", waves)
@@ -65,6 +66,12 @@ def mixed(a):
             dw = b["digests"].download(np.uint8, 20 * a.n).reshape(-1, 20)
             out["scheduled"]["%d_waves_share_below_%d" % (waves, share)] = {
                 "ms": round(min(msw), 3), "GBps": round(float(sizes.sum()) / min(msw) / 1e6, 1), "match": bool((dw == d1).all())}
+    # the library's own choice (both launches queued, the waves decide by the longest object against a SIMD's mean share)
+    h.set_option("sched_waves", 1); h.set_option("sched_share_below", 128); h.set_option("sched_tail_percent", 75)
+    b["digests"].upload(np.zeros(20 * a.n, dtype=np.uint8))
+    msa = h.time_hash_device(b, order=order, warmup=1, iters=a.iters)
+    da = b["digests"].download(np.uint8, 20 * a.n).reshape(-1, 20)
+    out["auto"] = {"ms": round(min(msa), 3), "GBps": round(float(sizes.sum()) / min(msa) / 1e6, 1), "match": bool((da == d1).all())}
     out["match_binned_vs_unbinned"] = bool((d0 == d1).all())
     for i in (0, 1, a.n // 2, a.n - 1, int(np.argmax(sizes))):
         assert d1[i].tobytes() == git_id(vit_amd.synth_bytes(0x5EED0004, i, int(sizes[i]))), i

@@ -14,6 +14,7 @@ import vit_amd  # noqa: E402
 
 h = vit_amd.Hasher((0,))
 h.set_option("sched_min_groups", 1)
+h.set_option("sched_tail_percent", 0)          # forced: this measures the launch, not the choice
 out = {}
 for label, hi in (("0..256B", 257), ("0..8KiB", 8193)):
     n = 1_000_000
@@ -28,6 +29,10 @@ for label, hi in (("0..256B", 257), ("0..8KiB", 8193)):
         h.set_option("sched_share_below", share)
         ms = h.time_hash_device(b, order=order, warmup=2, iters=10)
         res["waves %d share_below %d" % (waves, share)] = round(statistics.median(ms), 4)
+    h.set_option("sched_waves", 1); h.set_option("sched_share_below", 128); h.set_option("sched_tail_percent", 75)
+    h.set_option("sched_min_groups", 4096)
+    res["library's choice"] = round(statistics.median(h.time_hash_device(b, order=order, warmup=2, iters=10)), 4)
+    h.set_option("sched_tail_percent", 0); h.set_option("sched_min_groups", 1)
     out[label] = res
     del b, order
 print(json.dumps(out))

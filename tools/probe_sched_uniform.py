@@ -16,6 +16,7 @@ n = 1_000_000
 b = h.synth_arena("blob", 0x5EED0002, 0, n, 4096, slot_align=128)
 order = h.alloc(4 * n).upload(np.arange(n, dtype=np.uint32))
 h.set_option("sched_min_groups", 1)
+h.set_option("sched_tail_percent", 0)
 res = {}
 for rep in range(3):
     for waves in (0, 1, 2, 3, 4, 5):

@@ -22,6 +22,7 @@ while time.time() < t_end:
     h.set_option("chunk_object_multiple", int(rng.choice([0, 64, 8192])))
     h.set_option("sched_waves", int(rng.choice([0, 1, 2])))            # software-scheduled launch of binned chunks
     h.set_option("sched_min_groups", int(rng.choice([1, 16, 4096])))
+    h.set_option("sched_tail_percent", int(rng.choice([0, 1, 75])))
     h.set_option("sched_share_below", int(rng.choice([0, 128, 1 << 20])))
     h.set_option("pack_threads", int(rng.choice([3, 8, 16])))
     mode = int(rng.integers(0, 3))

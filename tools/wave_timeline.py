@@ -12,6 +12,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
 
 h = vit_amd.Hasher((0,))
 # VIT_SCHED_WAVES=0: hardware dispatch; 1..5: the software-scheduled launch with that many waves per SIMD
+h.set_option("sched_tail_percent", 0)          # the environment picks the launch, not the lengths
 for opt, env in (("sched_waves", "VIT_SCHED_WAVES"), ("sched_share_below", "VIT_SHARE_BELOW")):
     if os.environ.get(env) is not None:
         h.set_option(opt, int(os.environ[env]))

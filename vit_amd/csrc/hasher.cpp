@@ -71,6 +71,7 @@ struct Queue {
     uint32_t  status_seen = 0;                             // bits the chunks of host-memory calls have brought back
     vit::SchedState* d_sched = nullptr;                    // device: kSchedStates states of the software-scheduled launch,
     uint32_t  sched_next = 0;                              // used in turn (a launch leaves its state all zero again)
+    uint32_t  simds = 1024;                                // SIMDs of the device
     void*     scratch = nullptr;                           // this DEVICE's address of the kernels' file-scope scratch array
                                                            // (vit_hash_arena_device_static); shared by every queue on the device
     uint64_t  chunks_this_call = 0;
@@ -111,6 +112,8 @@ struct vit_hasher {
     uint32_t sched_waves = 1;                             // resident waves per SIMD of that launch (1 or 2)
     uint32_t sched_min_groups = 4096;
     uint32_t sched_share_below = 128;                     // blocks: a SIMD's spare waves work only beside a leader group this short
+    uint32_t sched_tail_percent = 75;                     // ... and only if the longest object is at least this share of a SIMD's
+                                                          // mean work (vit::tail_dominates); 0 = whatever the lengths
     int pack_threads = 8;                                 // the host thread budget of a call, helpers included
     std::unique_ptr<vit::WorkPool> pool;
     // Rates the auto policy balances with, bytes per second; 0 = not measured
@@ -273,20 +276,35 @@ vit::DeviceBatch make_batch(const Queue& q, const void* d_arena, uint64_t arena_
     b.digests = d_dig;
     b.status = q.d_status;
     b.wave_trace = q.wave_trace;
+    b.gate_percent = 0; b.gate_simds = 0;
     return b;
 }
 
 // The SHA-1 launch of a batch: software-scheduled when the batch is in binned
 // order and large enough to fill the resident grid several times, else plain.
+// The scheduled launch pays only where the batch's longest object is long against
+// a SIMD's mean share of the work (vit::tail_dominates; batches of short objects
+// lose a factor of three under it).  longest_blocks: that object's block count
+// when the host has seen the lengths, 0 when they exist in device memory only —
+// then both launches go out and their waves decide (DeviceBatch::gate_percent).
 // staging_set: 0..2 for a chunk of that staging set, -1 for a caller's device-resident arena.
-hipError_t launch_hash(vit_hasher* h, Queue& q, const vit::DeviceBatch& b, hipStream_t stream, int staging_set)
+hipError_t launch_hash(vit_hasher* h, Queue& q, const vit::DeviceBatch& b, hipStream_t stream, int staging_set,
+                       uint64_t longest_blocks)
 {
     const uint64_t groups = (uint64_t(b.n) + 63) / 64;
-    if (h->kernel == VIT_KERNEL_LDS && b.order && h->sched_waves && groups >= h->sched_min_groups) {
-        const uint32_t state = staging_set >= 0 ? uint32_t(staging_set) : 3u + q.sched_next++ % (kSchedStates - 3u);
-        return vit::launch_sha1_sched(b, &q.d_sched[state], h->sched_waves, h->sched_share_below, stream);
-    }
-    return vit::launch_sha1(vit::KernelVariant(h->kernel), b, stream);
+    const vit::KernelVariant v = vit::KernelVariant(h->kernel);
+    if (h->kernel != VIT_KERNEL_LDS || !b.order || !h->sched_waves || groups < h->sched_min_groups)
+        return vit::launch_sha1(v, b, stream);
+    const uint32_t pct = h->sched_tail_percent;
+    if (pct && longest_blocks && !vit::tail_dominates(longest_blocks, b.arena_bytes, q.simds, pct))
+        return vit::launch_sha1(v, b, stream);
+    const uint32_t state = staging_set >= 0 ? uint32_t(staging_set) : 3u + q.sched_next++ % (kSchedStates - 3u);
+    if (!pct || longest_blocks) return vit::launch_sha1_sched(b, &q.d_sched[state], h->sched_waves, h->sched_share_below, stream);
+    vit::DeviceBatch gated = b;
+    gated.gate_percent = pct;
+    gated.gate_simds = q.simds;
+    const hipError_t e = vit::launch_sha1_sched(gated, &q.d_sched[state], h->sched_waves, h->sched_share_below, stream);
+    return e != hipSuccess ? e : vit::launch_sha1(v, gated, stream);
 }
 
 // Collect a finished chunk: wait for it, scatter its digests to the caller and
@@ -344,8 +362,10 @@ int launch_chunk(Queue& q, vit_hasher* h, Staging& s, hipStream_t stream, const 
     HIP_TRYQ(q, hipMemcpyAsync(s.d_arena, src, bytes, hipMemcpyHostToDevice, stream));
     HIP_TRYQ(q, hipMemcpyAsync(s.d_meta, s.h_meta, meta_bytes + (binned ? meta_bytes / 3 : 0), hipMemcpyHostToDevice, stream));
     if (trace) HIP_TRYQ(q, hipEventRecord(s.mark[1], stream));
+    // the host packed or checked these objects: it knows the longest (first in binned order)
+    const uint64_t longest = cnt ? (binned ? s.h_nb[s.h_order[0]] : s.h_nb[0]) : 0;
     HIP_TRYQ(q, launch_hash(h, q, make_batch(q, s.d_arena, bytes, s.d_off, s.d_nb, binned ? s.d_order : nullptr, cnt,
-                                             s.d_dig), stream, int(&s - q.st)));
+                                             s.d_dig), stream, int(&s - q.st), std::max<uint64_t>(longest, 1)));
     if (trace) HIP_TRYQ(q, hipEventRecord(s.mark[2], stream));
     HIP_TRYQ(q, hipMemcpyAsync(s.h_dig, s.d_dig, cnt * 20, hipMemcpyDeviceToHost, stream));
     HIP_TRYQ(q, hipMemcpyAsync(s.h_status, q.d_status, 4, hipMemcpyDeviceToHost, stream));
@@ -671,6 +691,7 @@ int vit_hasher_create(const int* device_ids, int n_devices, vit_hasher** out)
         if (r == hipSuccess) r = hipSetDevice(ids[k]);
         for (hipStream_t& st : q.stream)
             if (r == hipSuccess) r = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (r == hipSuccess) r = vit::device_simds(&q.simds);
         if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void**>(&q.d_status), kStatusBytes);
         if (r == hipSuccess) r = hipHostMalloc(reinterpret_cast<void**>(&q.h_status), 64, hipHostMallocDefault);
         if (r == hipSuccess) r = hipMalloc(reinterpret_cast<void**>(&q.d_sched), sizeof(vit::SchedState) * kSchedStates);
@@ -748,6 +769,7 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     else if (k == "sched_waves") h->sched_waves = uint32_t(value > 8 ? 8 : value);
     else if (k == "sched_share_below") h->sched_share_below = uint32_t(value > 0xFFFFFFFEull ? 0xFFFFFFFEu : value);
     else if (k == "sched_min_groups") h->sched_min_groups = uint32_t(value > 0xFFFFFFFFull ? 0xFFFFFFFFu : value);
+    else if (k == "sched_tail_percent") h->sched_tail_percent = uint32_t(value > 1000 ? 1000 : value);
     else return fail(h, VIT_ERR_ARG, "unknown option '%s'", name);
     return VIT_OK;
     VIT_NOEXCEPT_END(h)
@@ -1079,7 +1101,7 @@ int vit_hash_arena_device(vit_hasher* h, int dev, const void* d_arena, uint64_t 
     if (reinterpret_cast<uintptr_t>(d_arena) & 15) return fail(h, VIT_ERR_RANGE, "arena not 16-byte aligned");
     HIP_TRY(h, hipSetDevice(q->device));
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : q->stream[0];
-    HIP_TRY(h, launch_hash(h, *q, make_batch(*q, d_arena, arena_bytes, d_offsets, d_nblocks, d_order, n, d_digests), s, -1));
+    HIP_TRY(h, launch_hash(h, *q, make_batch(*q, d_arena, arena_bytes, d_offsets, d_nblocks, d_order, n, d_digests), s, -1, 0));
     ++h->launches; h->objects_gpu += n;
     return VIT_OK;
 }
@@ -1104,7 +1126,8 @@ int vit_hash_arena_device_static(vit_hasher* h, int dev, const void* d_arena, ui
     const bool sched = h->kernel == VIT_KERNEL_LDS && h->sched_waves && (n + 63) / 64 >= h->sched_min_groups;
     HIP_TRY(h, vit::launch_sha1_static(vit::KernelVariant(h->kernel),
                                        make_batch(*q, d_arena, arena_bytes, d_offsets, d_nblocks, nullptr, n, d_digests),
-                                       q->scratch, sched ? h->sched_waves : 0, h->sched_share_below, s));
+                                       q->scratch, sched ? h->sched_waves : 0, h->sched_share_below,
+                                       h->sched_tail_percent, s));
     ++h->launches; h->objects_gpu += n;
     return VIT_OK;
 }

@@ -28,7 +28,24 @@ struct DeviceBatch {
     uint32_t*       status;       // device word, OR-ed with STATUS_* bits on bad input
     uint64_t*       wave_trace;   // diagnostics, normally nullptr: 4 words per wave (start and end of the wave on the
                                   // 100 MHz wall clock, hardware id, longest object in blocks)
+    // Launch gate, for batches whose lengths the host never saw.  gate_percent == 0: the launch runs.  Otherwise
+    // the SAME batch is launched twice, through the software-scheduled kernel and through the plain one, and every
+    // wave of both evaluates tail_dominates() on the batch's first (longest) object: the scheduled launch runs only
+    // if it holds, the plain one only if it does not; the waves of the other leave at once.
+    uint32_t        gate_percent;
+    uint32_t        gate_simds;
 };
+
+// Does the batch have a tail worth scheduling for?  The scheduled launch keeps ONE wave per SIMD busy, which costs
+// about 1.32 us per 64-byte block and wave where five waves sharing the SIMD cost 1.05 us between them, but it never
+// lets a long group share its SIMD; under the hardware dispatcher a long group does, and the launch then lasts about
+// 1.7 us per block of the longest object.  With W = the mean work of a SIMD in wave-blocks (arena bytes / 64 bytes /
+// 64 lanes / SIMDs) the scheduled launch therefore wins once the longest object exceeds about 0.78 W; `percent` is
+// that ratio (default 75).
+__host__ __device__ inline bool tail_dominates(uint64_t longest_blocks, uint64_t arena_bytes, uint32_t simds, uint32_t percent)
+{
+    return longest_blocks * 4096ull * simds * 100ull >= arena_bytes * percent;
+}
 
 enum : uint32_t {
     STATUS_OUT_OF_BOUNDS = 1u,    // offsets[i] + 64*nblocks[i] > arena_bytes
@@ -91,8 +108,11 @@ hipError_t bin_order_device(const uint32_t* d_nblocks, uint32_t n, uint32_t* d_o
 constexpr uint32_t STATIC_MAX_OBJECTS = 1u << 21;
 hipError_t static_scratch_address(void** out);        // hipGetSymbolAddress for the current device
 uint64_t static_scratch_bytes();
+// sched_waves != 0: the scheduled launch may be used; tail_percent != 0: the waves decide (DeviceBatch::gate_percent).
 hipError_t launch_sha1_static(KernelVariant v, DeviceBatch b, void* scratch_ptr, uint32_t sched_waves,
-                              uint32_t sched_share_below, hipStream_t stream);
+                              uint32_t sched_share_below, uint32_t tail_percent, hipStream_t stream);
+// SIMDs of the current device (compute units x 4).
+hipError_t device_simds(uint32_t* out);
 
 // Compute-only ceiling: every lane runs `blocks_per_lane` SHA-1 compressions on
 // register-resident data (no loads in the loop).  out: one dword per lane.

@@ -330,9 +330,19 @@ __device__ __forceinline__ void hash_group(const DeviceBatch& b, uint8_t* const 
     if (b.wave_trace && lane == 0) trace_wave(b.wave_trace, group, trace_t0, max_nb);
 }
 
+// The launch gate (DeviceBatch::gate_percent): wave-uniform, two dependent scalar loads.
+__device__ __forceinline__ bool gate_picks_scheduled(const DeviceBatch& b)
+{
+    uint32_t first = 0;
+    if (b.order) first = b.order[0];                    // binned order: the first object is the longest
+    const uint32_t longest = first < b.n ? b.nblocks[first] : 0u;
+    return tail_dominates(longest, b.arena_bytes, b.gate_simds, b.gate_percent);
+}
+
 template <int BPS, int WPB>
 __global__ __launch_bounds__(64 * WPB, BPS == 4 ? 2 : (BPS == 1 ? 4 : 5)) void sha1_lds_kernel(DeviceBatch b)
 {
+    if (b.gate_percent && gate_picks_scheduled(b)) return;
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[WPB][64 * 64 * BPS];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -393,6 +403,7 @@ __global__ __launch_bounds__(64 * WPB, 2) void sha1_sched_kernel(DeviceBatch b, 
     __shared__ __attribute__((aligned(16))) uint8_t stage_all[WPB][64 * 64 * BPS];
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t* const stage = stage_all[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+    if (b.gate_percent && !gate_picks_scheduled(b)) return;      // before anything touches the state: it stays all zero
     const uint32_t key = physical_simd();
     uint32_t rank = 0;
     if (lane == 0) rank = atomicAdd(&st->simd_waves[key], 1u);
@@ -432,6 +443,15 @@ __global__ __launch_bounds__(64 * WPB, 2) void sha1_sched_kernel(DeviceBatch b, 
         __threadfence();
         if (atomicAdd(&st->exited, 1u) == nwaves - 1u) { atomicExch(&st->next, 0u); atomicExch(&st->exited, 0u); }
     }
+}
+
+hipError_t device_simds(uint32_t* out)
+{
+    int dev = 0, cus = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e == hipSuccess) *out = uint32_t(cus) * 4u;
+    return e;
 }
 
 hipError_t launch_sha1_sched(const DeviceBatch& b, SchedState* state, uint32_t waves_per_simd, uint32_t share_below,
@@ -725,7 +745,7 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const uint32_t* nblock
 }
 
 hipError_t launch_sha1_static(KernelVariant v, DeviceBatch b, void* scratch_ptr, uint32_t sched_waves,
-                              uint32_t sched_share_below, hipStream_t stream)
+                              uint32_t sched_share_below, uint32_t tail_percent, hipStream_t stream)
 {
     if (b.n == 0) return hipSuccess;
     if (b.n > STATIC_MAX_OBJECTS || !scratch_ptr) return hipErrorInvalidValue;
@@ -748,7 +768,12 @@ hipError_t launch_sha1_static(KernelVariant v, DeviceBatch b, void* scratch_ptr,
     // The scheduler's state must be all zero at launch: a launch leaves it so, but a
     // launch that was cut short (device reset, aborted stream) would not have.
     if ((e = hipMemsetAsync(s + kScratchSched, 0, sizeof(SchedState), stream)) != hipSuccess) return e;
-    return launch_sha1_sched(b, reinterpret_cast<SchedState*>(s + kScratchSched), sched_waves, sched_share_below, stream);
+    // The order exists on the device only: with a tail criterion both launches go out and their waves pick one.
+    b.gate_percent = tail_percent;
+    if (tail_percent && (e = device_simds(&b.gate_simds)) != hipSuccess) return e;
+    e = launch_sha1_sched(b, reinterpret_cast<SchedState*>(s + kScratchSched), sched_waves, sched_share_below, stream);
+    if (e == hipSuccess && tail_percent) e = launch_sha1(v, b, stream);
+    return e;
 }
 
 // --------------------------------------------------------- compute ceiling --
