@@ -141,7 +141,7 @@ def end_to_end(args, world, resident_digests):
             # CPUs this process may run on
             h.set_option("pack_threads", max(2, min(len(os.sched_getaffinity(0)), 16 * len(ids))))
             dig, (total_ns, pack_ns, on_gpu, on_host, bytes_host, h2d) = time_host_batch(h, ptrs, sizes, m)
-            rates = {k: h.stat(k) for k in ("lane_rate", "core_rate", "copy_rate", "pack_rate")}
+            rates = {k: h.stat(k) for k in ("lane_rate", "core_rate", "core_rate_multi", "copy_rate", "pack_rate")}
             threads = h.stat("pool_threads") + (len(ids) if len(ids) > 1 else 1)
         mv = memoryview(buf)
         ok = True
@@ -156,7 +156,8 @@ def end_to_end(args, world, resident_digests):
             "objects_gpu": on_gpu, "objects_host": on_host, "bytes_host": bytes_host, "bytes_h2d": h2d,
             "host_threads": threads, "measured_rates_bytes_per_s": rates,
             "bound": "GPU side: %d x PCIe (%.0f GB/s spec each) or the host's DRAM/packing threads, whichever is lower; "
-                     "host side: %d threads x the measured core rate; the two sides run concurrently and add up"
+                     "host side: %d threads x the measured core rate (core_rate_multi where objects outnumber threads: four SHA-1 "
+                     "streams interleaved per core); the two sides run concurrently and add up"
                      % (len(ids), PCIE_GBS, threads),
             "workload": "BASELINE configs[3] sizes (lognormal, 15 KB mean, <= 32 MiB), objects above the balance point "
                         "hashed on host threads meanwhile",

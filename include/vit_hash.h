@@ -68,7 +68,7 @@ int vit_hasher_device_count(const vit_hasher *h);
  *                         0 = never, every object takes a GPU lane
  *  "host_auto"            1 (default): derive that threshold per call by
  *                         balancing the two sides: from the longest object
- *                         down, objects of 64 KiB or more move to the host
+ *                         down, objects of 16 KiB or more move to the host
  *                         threads while the host side (its bytes over the
  *                         threads; its longest object on one core) would
  *                         still finish before the GPU side (its bytes over
@@ -84,8 +84,12 @@ int vit_hasher_device_count(const vit_hasher *h);
  *                         calling thread and the per-queue threads count against it,
  *                         so the number of busy threads does not grow with the
  *                         number of GPUs (default: the cores, at most 16)
- *  "lane_rate" "core_rate" "copy_rate" "pack_rate"
- *                         bytes per second of one GPU lane, one host core hashing,
+ *  "lane_rate" "core_rate" "core_rate_multi" "copy_rate" "pack_rate"
+ *                         bytes per second of one GPU lane, one host core hashing one
+ *                         object, one host core hashing four objects side by side (their
+ *                         SHA-1 streams interleaved: where the CPU pipelines its SHA
+ *                         instructions that is about twice the bytes, and host-lane
+ *                         objects that outnumber the threads then go in such groups),
  *                         one pinned host-to-device copy and one host core packing:
  *                         what "host_auto" balances with.  They are measured on this
  *                         machine the first time a batch needs them (a few ms);
@@ -222,7 +226,7 @@ int vit_shard_plan(const uint32_t *nblocks, uint64_t n, int n_queues, uint32_t *
  * length len[i]) would be hashed on host threads beside the GPU batch, given
  * bytes-per-second rates of one GPU lane, one host core hashing, one pinned
  * host-to-device copy and one host core packing, the number of device queues and
- * the host thread budget.  Objects under 64 KiB never move; from the longest
+ * the host thread budget.  Objects under 16 KiB never move; from the longest
  * down, objects move while the host side (hashing what moved plus packing what
  * stayed, over the threads) would still finish before the GPU side (its bytes
  * through 0.8 x copy rate per queue, never less than its longest object on one

@@ -54,6 +54,14 @@ int main() {
             std::free(raw);
         }
         std::free(arena);
+        // the interleaved host lane (several objects' streams side by side on one core) against one stream at a time,
+        // framed and raw, on buffers of exact size and every count up to a few groups
+        for (const char* type : {static_cast<const char*>("blob"), static_cast<const char*>(nullptr)}) {
+            std::vector<uint8_t> got(size_t(n) * 20), want(size_t(n) * 20);
+            vit::host_object_ids(type, ptr.data(), len.data(), size_t(n), got.data());
+            for (int i = 0; i < n; ++i) vit::host_object_id(type, ptr[i], len[i], &want[size_t(i) * 20]);
+            if (got != want) { std::printf("interleaved host lane differs, round %d\n", round); return 1; }
+        }
     }
     std::puts("pack + host lane clean");
     return 0;

@@ -102,7 +102,7 @@ def test_uniform_batch_of_large_objects_is_shared_not_dumped_on_the_host(hasher)
     assert hasher.stat("last_host_objects") == on_host
     for i in (0, 1, n // 2, n - 1):
         assert got[i].tobytes() == hashlib.sha1(b"blob %d\0" % L + blobs[i].tobytes()).digest()
-    rates = {k: hasher.stat(k) for k in ("lane_rate", "core_rate", "copy_rate", "pack_rate")}
+    rates = {k: hasher.stat(k) for k in ("lane_rate", "core_rate", "core_rate_multi", "copy_rate", "pack_rate")}
     print("calibrated rates (bytes/s):", rates, "in", hasher.stat("calibrate_ns") / 1e6, "ms; split gpu/host", on_gpu, on_host)
     assert 10e6 < rates["lane_rate"] < 200e6 and 0.2e9 < rates["core_rate"] < 10e9
     assert 5e9 < rates["copy_rate"] < 100e9 and 1e9 < rates["pack_rate"] < 100e9
@@ -117,10 +117,12 @@ def test_uniform_batch_of_large_objects_is_shared_not_dumped_on_the_host(hasher)
         moved = {}
         for scale in (0.5, 2.0):
             hasher.set_option("core_rate", int(rates["core_rate"] * scale))
+            hasher.set_option("core_rate_multi", int(rates["core_rate_multi"] * scale))
             assert (hasher.hash_blobs(blobs) == got).all()
             moved[scale] = hasher.stat("last_host_objects")
         assert moved[0.5] < base < moved[2.0], (moved, base)
         hasher.set_option("core_rate", rates["core_rate"])
+        hasher.set_option("core_rate_multi", rates["core_rate_multi"])
         # a lane believed twice as fast keeps more objects on the GPU (or as many)
         hasher.set_option("lane_rate", int(rates["lane_rate"] * 2))
         hasher.hash_blobs(blobs[:200])

@@ -119,8 +119,9 @@ struct vit_hasher {
     // Rates the auto policy balances with, bytes per second; 0 = not measured
     // yet.  *_fixed: set through an option, never measured.
     double lane_rate = 0, core_rate = 0, copy_rate = 0, pack_rate = 0;
-    bool lane_fixed = false, core_fixed = false, copy_fixed = false, pack_fixed = false;
-    bool calibrated = false;
+    double core_rate_multi = 0;                           // one core, kHostStreams objects interleaved (sha1_host.h); <= core_rate: not used
+    bool lane_fixed = false, core_fixed = false, copy_fixed = false, pack_fixed = false, core_multi_fixed = false;
+    bool calibrated = false, host_calibrated = false;
     uint64_t calibrate_ns = 0;
     uint64_t fail_at_chunk = 0;                           // fault injection for tests: 0 = off
     std::atomic<uint64_t> objects_gpu{0}, objects_host{0}, bytes_host{0}, blocks_gpu{0}, bytes_h2d{0}, launches{0};
@@ -565,6 +566,41 @@ int read_status_word(vit_hasher* h, Queue& q, uint32_t* out)
     return VIT_OK;
 }
 
+// The two host hashing rates: one core on one SHA-1 stream, and on kHostStreams
+// streams interleaved.  About 5 ms, once per hasher; needed by the balance
+// (calibrate) and by the grouping of host-lane objects under any policy.
+void calibrate_host(vit_hasher* h)
+{
+    if (h->host_calibrated) return;
+    constexpr uint64_t kHost = 4ull << 20;
+    std::vector<uint8_t> src(kHost, 0x5A);
+    if (!h->core_fixed) {
+        double best = 1e30;
+        uint8_t d[20];
+        for (int r = 0; r < 2; ++r) {
+            const auto t = clk::now();
+            vit::host_object_id("blob", src.data(), kHost, d);
+            best = std::min(best, double(ns_since(t)) * 1e-9);
+        }
+        h->core_rate = double(kHost) / best;
+    }
+    if (!h->core_multi_fixed) {
+        // the same bytes as four objects side by side on this core
+        const uint8_t* four[vit::kHostStreams];
+        uint64_t lens[vit::kHostStreams];
+        uint8_t d[20 * vit::kHostStreams];
+        for (int k = 0; k < vit::kHostStreams; ++k) { four[k] = src.data() + size_t(k) * (kHost / vit::kHostStreams); lens[k] = kHost / vit::kHostStreams; }
+        double best = 1e30;
+        for (int r = 0; r < 2; ++r) {
+            const auto t = clk::now();
+            vit::host_object_ids("blob", four, lens, vit::kHostStreams, d);
+            best = std::min(best, double(ns_since(t)) * 1e-9);
+        }
+        h->core_rate_multi = double(kHost) / best;
+    }
+    h->host_calibrated = true;
+}
+
 // Measure, once per hasher and on its first queue, the four rates the auto
 // policy balances with (anything set through an option stays as set):
 //   core_rate  one host thread's SHA-1 (vit::host_object_id over 4 MiB)
@@ -586,16 +622,7 @@ int calibrate(vit_hasher* h, const uint8_t* sample, uint64_t sample_len)
     HIP_TRY(h, hipSetDevice(q.device));
     constexpr uint64_t kHost = 4ull << 20, kCopy = 32ull << 20;
     std::vector<uint8_t> src(kHost, 0x5A);
-    if (!h->core_fixed) {
-        double best = 1e30;
-        uint8_t d[20];
-        for (int r = 0; r < 2; ++r) {
-            const auto t = clk::now();
-            vit::host_object_id("blob", src.data(), kHost, d);
-            best = std::min(best, double(ns_since(t)) * 1e-9);
-        }
-        h->core_rate = double(kHost) / best;
-    }
+    calibrate_host(h);
     if (!h->pack_fixed || !h->copy_fixed) {
         Staging& s = q.st[0];
         if (ensure_arena(q, s, kCopy) != VIT_OK) return fail(h, VIT_ERR_NOMEM, "calibration: %s", q.err.c_str());
@@ -747,7 +774,7 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     if (!h || !name) return VIT_ERR_ARG;
     VIT_NOEXCEPT_BEGIN
     const std::string k(name);
-    auto rate = [&](double& r, bool& fixed) { r = double(value); fixed = value != 0; if (!value) h->calibrated = false; };
+    auto rate = [&](double& r, bool& fixed) { r = double(value); fixed = value != 0; if (!value) h->calibrated = h->host_calibrated = false; };
     if (k == "kernel") {
         if (value > 5) return fail(h, VIT_ERR_ARG, "unknown kernel %llu", (unsigned long long)value);
         h->kernel = int(value);
@@ -763,6 +790,7 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     }
     else if (k == "lane_rate") rate(h->lane_rate, h->lane_fixed);
     else if (k == "core_rate") rate(h->core_rate, h->core_fixed);
+    else if (k == "core_rate_multi") rate(h->core_rate_multi, h->core_multi_fixed);
     else if (k == "copy_rate") rate(h->copy_rate, h->copy_fixed);
     else if (k == "pack_rate") rate(h->pack_rate, h->pack_fixed);
     else if (k == "debug_fail_at_chunk") h->fail_at_chunk = value;
@@ -793,6 +821,7 @@ int vit_hasher_get_stat(const vit_hasher* h, const char* name, uint64_t* value)
     else if (k == "host_sha_accelerated") *value = vit::HostSha1::accelerated();
     else if (k == "lane_rate") *value = uint64_t(h->lane_rate);
     else if (k == "core_rate") *value = uint64_t(h->core_rate);
+    else if (k == "core_rate_multi") *value = uint64_t(h->core_rate_multi);
     else if (k == "copy_rate") *value = uint64_t(h->copy_rate);
     else if (k == "pack_rate") *value = uint64_t(h->pack_rate);
     else if (k == "calibrate_ns") *value = h->calibrate_ns;
@@ -845,7 +874,7 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
             uint64_t longest = 0;
             for (uint64_t i = 1; i < n; ++i) if (len[i] > len[longest]) longest = i;
             if (int rc = calibrate(h, data[longest], len[longest])) return rc;
-            vit::plan_host_split(len, n, vit::SplitRates{h->lane_rate, h->core_rate, h->copy_rate, h->pack_rate},
+            vit::plan_host_split(len, n, vit::SplitRates{h->lane_rate, h->core_rate, h->copy_rate, h->pack_rate, h->core_rate_multi},
                                  int(h->queues.size()), h->pack_threads, host_idx);
             if (!host_idx.empty()) threshold = len[host_idx.back()] - 1;
         }
@@ -889,6 +918,7 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
 
     // Oversized objects: one SHA-1 stream each on the pool's threads, at low
     // priority, beside the GPU batch; longest first, so the tail is short.
+    std::vector<uint32_t> host_group;                     // task g hashes host_idx[host_group[g] .. host_group[g+1])
     vit::WorkPool::Ticket host_work;
     // From the submit below on, the pool's workers hold references into this
     // frame: every path out waits for them first.
@@ -896,11 +926,35 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
         vit::WorkPool& pool; vit::WorkPool::Ticket& t;
         ~WaitHost() { if (t) pool.wait(t); }
     } wait_host{*h->pool, host_work};
+    // A core gets through more bytes with several objects' streams interleaved
+    // (sha1_host.h), where the machine's SHA instructions are pipelined: when the
+    // objects outnumber the threads, the objects after the longest few go in
+    // groups of up to kHostStreams neighbours in length order.  The longest stay
+    // alone: a group lasts as long as its objects' lengths added up, and an
+    // object of more than 1/8 of a thread's share would make its group the tail.
     if (!host_idx.empty()) {
-        std::stable_sort(host_idx.begin(), host_idx.end(), [&](uint64_t a, uint64_t b) { return len[a] > len[b]; });
-        host_work = h->pool->submit(vit::WorkPool::LOW, host_idx.size(), [&](size_t k) {
-            const uint64_t i = host_idx[k];
-            vit::host_object_id(type, data[i], len[i], digests + i * 20);
+        if (h->host_policy != 1)                          // the balance hands its list over longest first
+            std::stable_sort(host_idx.begin(), host_idx.end(), [&](uint64_t a, uint64_t b) { return len[a] > len[b]; });
+        const size_t nh = host_idx.size(), nt = size_t(h->pack_threads);
+        if (nh >= 2 * nt) calibrate_host(h);
+        size_t streams = 1;
+        if (h->core_rate_multi > 1.15 * h->core_rate && h->core_rate > 0) streams = std::min<size_t>(std::max<size_t>(nh / nt, 1), vit::kHostStreams);
+        const uint64_t alone_above = host_bytes / (8 * nt);
+        host_group.push_back(0);
+        for (size_t k = 0; k < nh;) {
+            const size_t take = (streams == 1 || len[host_idx[k]] > alone_above) ? 1 : std::min(streams, nh - k);
+            k += take;
+            host_group.push_back(uint32_t(k));
+        }
+        host_work = h->pool->submit(vit::WorkPool::LOW, host_group.size() - 1, [&](size_t g) {
+            const size_t b = host_group[g], cnt = host_group[g + 1] - b;
+            if (cnt == 1) { const uint64_t i = host_idx[b]; vit::host_object_id(type, data[i], len[i], digests + i * 20); return; }
+            const uint8_t* ptr[vit::kHostStreams];
+            uint64_t ln[vit::kHostStreams];
+            uint8_t out[20 * vit::kHostStreams];
+            for (size_t j = 0; j < cnt; ++j) { ptr[j] = data[host_idx[b + j]]; ln[j] = len[host_idx[b + j]]; }
+            vit::host_object_ids(type, ptr, ln, cnt, out);
+            for (size_t j = 0; j < cnt; ++j) std::memcpy(digests + host_idx[b + j] * 20, out + 20 * j, 20);
         });
         h->objects_host += host_idx.size();
         h->bytes_host += host_bytes;

@@ -143,7 +143,25 @@ void plan_host_split(const uint64_t* len, uint64_t n, const SplitRates& r, int q
         if (len[i] >= kHostSplitMin) cand.push_back(i);
     }
     if (cand.empty()) return;
-    std::stable_sort(cand.begin(), cand.end(), [&](uint64_t a, uint64_t b) { return len[a] > len[b]; });
+    // Longest first, equal lengths in index order: a stable LSD radix sort on the
+    // lengths (a slice of a large repository has hundreds of thousands of
+    // candidates per call; a comparison sort of them costs more than the hashing
+    // of a chunk).
+    {
+        uint64_t maxlen = 0;
+        for (uint64_t i : cand) maxlen = std::max(maxlen, len[i]);
+        std::vector<uint64_t> tmp(cand.size());
+        uint64_t* src = cand.data();
+        uint64_t* dst = tmp.data();
+        for (int shift = 0; shift < 64 && (maxlen >> shift); shift += 11) {
+            size_t count[2049] = {0};
+            for (size_t k = 0; k < cand.size(); ++k) ++count[(2047u - ((len[src[k]] >> shift) & 2047u)) + 1];
+            for (int d = 0; d < 2048; ++d) count[d + 1] += count[d];
+            for (size_t k = 0; k < cand.size(); ++k) dst[count[2047u - ((len[src[k]] >> shift) & 2047u)]++] = src[k];
+            std::swap(src, dst);
+        }
+        if (src != cand.data()) std::memcpy(cand.data(), src, cand.size() * sizeof(uint64_t));
+    }
     const double nt = double(threads);
     const double queue_rate = std::min(0.8 * r.copy * double(queues), r.pack * nt);
     const double longest = double(len[cand[0]]);
@@ -152,7 +170,11 @@ void plan_host_split(const uint64_t* len, uint64_t n, const SplitRates& r, int q
     for (uint64_t i : cand) {
         const double L = double(len[i]);
         const double gpu_time = std::max(gpu_bytes / queue_rate, L / r.lane);
-        const double host_time = std::max(((host_bytes + L) / r.core + (gpu_bytes - L) / r.pack) / nt, longest / r.core);
+        // streams a core would run side by side with this many objects moved: 1 .. 4
+        const double per_thread = double(moved + 1) / nt;
+        const double streams = per_thread < 1 ? 1 : (per_thread > 4 ? 4 : per_thread);
+        const double core_eff = r.core_multi > r.core ? r.core + (r.core_multi - r.core) * (streams - 1) / 3 : r.core;
+        const double host_time = std::max(((host_bytes + L) / core_eff + (gpu_bytes - L) / r.pack) / nt, longest / r.core);
         if (host_time >= gpu_time) break;
         gpu_bytes -= L; host_bytes += L;
         ++moved;

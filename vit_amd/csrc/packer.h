@@ -33,8 +33,12 @@ bool bin_order(const uint32_t* nblocks, uint64_t n, uint32_t* order);
 //              never less than the longest moved object on one core.
 // Objects move one by one in (length, index) order, so a run of equal lengths
 // may be split between the two sides.  out: the moved indices, longest first.
-struct SplitRates { double lane, core, copy, pack; };
-constexpr uint64_t kHostSplitMin = 64u << 10;
+// core_multi (0 = none): what one core gets through when it runs kHostStreams
+// objects' SHA-1 streams interleaved (sha1_host.h); the host side counts on it
+// in proportion to the moved objects per thread (one object per thread: `core`,
+// four or more: `core_multi`).
+struct SplitRates { double lane, core, copy, pack; double core_multi = 0; };
+constexpr uint64_t kHostSplitMin = 16u << 10;
 void plan_host_split(const uint64_t* len, uint64_t n, const SplitRates& r, int queues, int threads,
                      std::vector<uint64_t>& out);
 

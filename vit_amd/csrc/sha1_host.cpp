@@ -1,6 +1,7 @@
 // sha1_host.cpp — streaming SHA-1 on a host core (see sha1_host.h for its role).
 #include "sha1_host.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -80,6 +81,53 @@ void blocks_shani(uint32_t h[5], const uint8_t* p, size_t nblocks)
     h[4] = uint32_t(_mm_extract_epi32(e, 3));
 }
 
+// S independent streams, n blocks each, instruction streams interleaved group
+// by group so that one stream's sha1rnds4 issues while another's is in flight.
+template <int S>
+__attribute__((target("sha,sse4.1,ssse3")))
+void blocks_shani_multi(uint32_t* const* hs, const uint8_t** ps, size_t nblocks)
+{
+    const __m128i bswap = _mm_set_epi64x(0x0001020304050607ll, 0x08090a0b0c0d0e0fll);
+    __m128i abcd[S], e[S];
+    const uint8_t* p[S];
+    for (int s = 0; s < S; ++s) {
+        abcd[s] = _mm_shuffle_epi32(_mm_loadu_si128(reinterpret_cast<const __m128i*>(hs[s])), 0x1B);
+        e[s] = _mm_set_epi32(int(hs[s][4]), 0, 0, 0);
+        p[s] = ps[s];
+    }
+    while (nblocks--) {
+        __m128i abcd0[S], e0[S], m[S][4], prev[S], cur[S];
+        for (int s = 0; s < S; ++s) {
+            abcd0[s] = abcd[s]; e0[s] = e[s]; prev[s] = abcd[s];
+            for (int i = 0; i < 4; ++i)
+                m[s][i] = _mm_shuffle_epi8(_mm_loadu_si128(reinterpret_cast<const __m128i*>(p[s] + 16 * i)), bswap);
+        }
+#define VIT_GM(g)                                                                                      \
+        _Pragma("GCC unroll 4") for (int s = 0; s < S; ++s) {                                          \
+            cur[s] = (g) == 0 ? _mm_add_epi32(e[s], m[s][0]) : _mm_sha1nexte_epu32(prev[s], m[s][(g) & 3]); \
+            prev[s] = abcd[s];                                                                         \
+            abcd[s] = _mm_sha1rnds4_epu32(abcd[s], cur[s], (g) / 5);                                    \
+            if ((g) < 16)                                                                              \
+                m[s][(g) & 3] = _mm_sha1msg2_epu32(                                                    \
+                    _mm_xor_si128(_mm_sha1msg1_epu32(m[s][(g) & 3], m[s][((g) + 1) & 3]), m[s][((g) + 2) & 3]), \
+                    m[s][((g) + 3) & 3]);                                                              \
+        }
+        VIT_GM(0)  VIT_GM(1)  VIT_GM(2)  VIT_GM(3)  VIT_GM(4)  VIT_GM(5)  VIT_GM(6)  VIT_GM(7)  VIT_GM(8)  VIT_GM(9)
+        VIT_GM(10) VIT_GM(11) VIT_GM(12) VIT_GM(13) VIT_GM(14) VIT_GM(15) VIT_GM(16) VIT_GM(17) VIT_GM(18) VIT_GM(19)
+#undef VIT_GM
+        for (int s = 0; s < S; ++s) {
+            e[s] = _mm_sha1nexte_epu32(prev[s], e0[s]);
+            abcd[s] = _mm_add_epi32(abcd[s], abcd0[s]);
+            p[s] += 64;
+        }
+    }
+    for (int s = 0; s < S; ++s) {
+        _mm_storeu_si128(reinterpret_cast<__m128i*>(hs[s]), _mm_shuffle_epi32(abcd[s], 0x1B));
+        hs[s][4] = uint32_t(_mm_extract_epi32(e[s], 3));
+        ps[s] = p[s];
+    }
+}
+
 bool cpu_has_sha()
 {
     static const bool yes = __builtin_cpu_supports("sha") && __builtin_cpu_supports("sse4.1") &&
@@ -139,16 +187,87 @@ void HostSha1::finish(uint8_t out[20])
     }
 }
 
+namespace {
+void feed_header(HostSha1& s, const char* type, uint64_t len)
+{
+    if (!type) return;                                    // nullptr: a raw buffer, no Git framing
+    char hdr[40];
+    int hl = std::snprintf(hdr, sizeof hdr, "%s %llu", type, static_cast<unsigned long long>(len)) + 1;
+    s.update(hdr, size_t(hl));
+}
+}  // namespace
+
 void host_object_id(const char* type, const uint8_t* content, uint64_t len, uint8_t out[20])
 {
     HostSha1 s;
-    if (type) {                                           // nullptr: a raw buffer, no Git framing
-        char hdr[40];
-        int hl = std::snprintf(hdr, sizeof hdr, "%s %llu", type, static_cast<unsigned long long>(len)) + 1;
-        s.update(hdr, size_t(hl));
-    }
+    feed_header(s, type, len);
     s.update(content, size_t(len));
     s.finish(out);
+}
+
+void host_object_ids(const char* type, const uint8_t* const* content, const uint64_t* len, size_t count, uint8_t* out)
+{
+#if defined(__x86_64__)
+    const bool interleave = cpu_has_sha();
+#else
+    const bool interleave = false;
+#endif
+    for (size_t first = 0; first < count; first += kHostStreams) {
+        const int k = int(count - first < size_t(kHostStreams) ? count - first : size_t(kHostStreams));
+        if (k == 1 || !interleave) {
+            for (int j = 0; j < k; ++j) host_object_id(type, content[first + j], len[first + j], out + (first + j) * 20);
+            continue;
+        }
+#if defined(__x86_64__)
+        // Head of every stream through the buffered path: the header and as much
+        // content as completes its block.  From there whole blocks come straight
+        // from the caller's memory, in lock step over the streams that still have
+        // any; what is left at the end (under 64 bytes, and the padding) goes
+        // through the buffered path again.
+        HostSha1 st[kHostStreams];
+        const uint8_t* p[kHostStreams];
+        uint64_t blocks_left[kHostStreams], tail[kHostStreams];
+        for (int j = 0; j < k; ++j) {
+            const uint8_t* c = content[first + j];
+            uint64_t n = len[first + j];
+            feed_header(st[j], type, n);
+            const uint64_t fill = std::min<uint64_t>(n, st[j].to_block_boundary());
+            st[j].update(c, size_t(fill));
+            c += fill; n -= fill;
+            if (st[j].to_block_boundary()) { p[j] = c; blocks_left[j] = 0; tail[j] = 0; continue; }   // shorter than its first block
+            p[j] = c;
+            blocks_left[j] = n / 64;
+            tail[j] = n % 64;
+        }
+        for (;;) {
+            int live[kHostStreams], nl = 0;
+            uint64_t step = ~0ull;
+            for (int j = 0; j < k; ++j)
+                if (blocks_left[j]) { live[nl++] = j; if (blocks_left[j] < step) step = blocks_left[j]; }
+            if (nl == 0) break;
+            uint32_t* hs[kHostStreams];
+            const uint8_t* ps[kHostStreams];
+            for (int a = 0; a < nl; ++a) { hs[a] = st[live[a]].state(); ps[a] = p[live[a]]; }
+            // size_t steps: a stream of more than 2^32 blocks on a 32-bit size_t is not a case x86-64 has
+            switch (nl) {
+            case 1: blocks_shani(hs[0], ps[0], size_t(step)); ps[0] += step * 64; break;
+            case 2: blocks_shani_multi<2>(hs, ps, size_t(step)); break;
+            case 3: blocks_shani_multi<3>(hs, ps, size_t(step)); break;
+            default: blocks_shani_multi<4>(hs, ps, size_t(step)); break;
+            }
+            for (int a = 0; a < nl; ++a) {
+                const int j = live[a];
+                p[j] = ps[a];
+                blocks_left[j] -= step;
+                st[j].account_blocks(step);
+            }
+        }
+        for (int j = 0; j < k; ++j) {
+            st[j].update(p[j], size_t(tail[j]));
+            st[j].finish(out + (first + j) * 20);
+        }
+#endif
+    }
 }
 
 }  // namespace vit
