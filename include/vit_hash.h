@@ -73,6 +73,11 @@ int vit_hasher_device_count(const vit_hasher *h);
  *                         threads; its longest object on one core) would
  *                         still finish before the GPU side (its bytes over
  *                         pack + PCIe; its longest object on one lane)
+ *  "host_min_bytes"       under "host_auto", objects shorter than this never move to the
+ *                         host threads (default 16 KiB: batches of small files, the bulk of a
+ *                         worktree, stay the GPU's, and the host threads stay free for
+ *                         reads, deflate and stores; 1 lets the balance share any batch,
+ *                         which a pure hashing workload from host memory gains from)
  *  "chunk_bytes"          smallest pinned staging buffer per queue and stream
  *                         (default 64 MiB); chunks grow with the longest
  *                         object they may hold, up to 1 GiB

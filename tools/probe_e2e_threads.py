@@ -28,4 +28,12 @@ with vit_amd.Hasher((0,)) as h:
             _, (total_ns, pack_ns, *_rest) = bench.time_host_batch(h, ptrs, sizes, n, runs=5)
             out["chunk %3d MiB, %2d threads" % (chunk_mb, threads)] = {
                 "GBps": round(n * L / total_ns, 2), "total_ms": round(total_ns / 1e6, 2), "pack_ms": round(pack_ns / 1e6, 2)}
+    # the host lane's share of a uniform batch, were small objects allowed to move (default: 16 KiB and up only)
+    h.set_option("chunk_bytes", 64 << 20)
+    h.set_option("pack_threads", 16)
+    for min_bytes in (16 << 10, 1):
+        h.set_option("host_min_bytes", min_bytes)
+        _, (total_ns, pack_ns, on_gpu, on_host, *_r) = bench.time_host_batch(h, ptrs, sizes, n, runs=5)
+        out["host_min_bytes %d" % min_bytes] = {"GBps": round(n * L / total_ns, 2), "total_ms": round(total_ns / 1e6, 2),
+                                                "objects_gpu": on_gpu, "objects_host": on_host}
 print(json.dumps(out, indent=1))

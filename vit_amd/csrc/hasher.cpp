@@ -104,6 +104,7 @@ struct vit_hasher {
     // (balanced per batch, see hash_batch), 2 fixed threshold.
     int host_policy = 1;
     uint64_t host_threshold = 0;
+    uint64_t host_min_bytes = vit::kHostSplitMin;        // auto: objects shorter than this stay on the GPU
     uint64_t chunk_bytes = 64ull << 20;
     uint64_t chunk_object_multiple = 8192;
     bool trace = false;
@@ -779,6 +780,7 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
         if (value > 5) return fail(h, VIT_ERR_ARG, "unknown kernel %llu", (unsigned long long)value);
         h->kernel = int(value);
     } else if (k == "host_threshold_bytes") { h->host_threshold = value; h->host_policy = value ? 2 : 0; }
+    else if (k == "host_min_bytes") h->host_min_bytes = value;
     else if (k == "host_auto") { h->host_policy = value ? 1 : (h->host_threshold ? 2 : 0); }
     else if (k == "chunk_bytes") h->chunk_bytes = value < (1u << 20) ? (1u << 20) : value;
     else if (k == "chunk_object_multiple") h->chunk_object_multiple = value;
@@ -869,12 +871,12 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
     if (h->host_policy == 2) threshold = h->host_threshold;
     else if (h->host_policy == 1) {
         bool any = false;
-        for (uint64_t i = 0; i < n && !any; ++i) any = len[i] >= vit::kHostSplitMin;
+        for (uint64_t i = 0; i < n && !any; ++i) any = len[i] >= h->host_min_bytes;
         if (any) {
             uint64_t longest = 0;
             for (uint64_t i = 1; i < n; ++i) if (len[i] > len[longest]) longest = i;
             if (int rc = calibrate(h, data[longest], len[longest])) return rc;
-            vit::plan_host_split(len, n, vit::SplitRates{h->lane_rate, h->core_rate, h->copy_rate, h->pack_rate, h->core_rate_multi},
+            vit::plan_host_split(len, n, vit::SplitRates{h->lane_rate, h->core_rate, h->copy_rate, h->pack_rate, h->core_rate_multi, h->host_min_bytes},
                                  int(h->queues.size()), h->pack_threads, host_idx);
             if (!host_idx.empty()) threshold = len[host_idx.back()] - 1;
         }
@@ -918,7 +920,8 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
 
     // Oversized objects: one SHA-1 stream each on the pool's threads, at low
     // priority, beside the GPU batch; longest first, so the tail is short.
-    std::vector<uint32_t> host_group;                     // task g hashes host_idx[host_group[g] .. host_group[g+1])
+    std::vector<uint32_t> host_group;                     // group g = host_idx[host_group[g] .. host_group[g+1]): streams run side by side
+    std::vector<uint32_t> host_task;                      // pool task t = groups [host_task[t], host_task[t+1])
     vit::WorkPool::Ticket host_work;
     // From the submit below on, the pool's workers hold references into this
     // frame: every path out waits for them first.
@@ -946,15 +949,27 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
             k += take;
             host_group.push_back(uint32_t(k));
         }
-        host_work = h->pool->submit(vit::WorkPool::LOW, host_group.size() - 1, [&](size_t g) {
-            const size_t b = host_group[g], cnt = host_group[g + 1] - b;
-            if (cnt == 1) { const uint64_t i = host_idx[b]; vit::host_object_id(type, data[i], len[i], digests + i * 20); return; }
-            const uint8_t* ptr[vit::kHostStreams];
-            uint64_t ln[vit::kHostStreams];
-            uint8_t out[20 * vit::kHostStreams];
-            for (size_t j = 0; j < cnt; ++j) { ptr[j] = data[host_idx[b + j]]; ln[j] = len[host_idx[b + j]]; }
-            vit::host_object_ids(type, ptr, ln, cnt, out);
-            for (size_t j = 0; j < cnt; ++j) std::memcpy(digests + host_idx[b + j] * 20, out + 20 * j, 20);
+        // One pool task = consecutive groups of at least kHostTaskBytes in all: claiming a
+        // task takes the pool's lock, which sixteen threads claiming 16 KiB objects one
+        // group at a time would spend their time waiting for.
+        constexpr uint64_t kHostTaskBytes = 1u << 20;
+        host_task.push_back(0);
+        uint64_t acc = 0;
+        for (size_t g = 0; g + 1 < host_group.size(); ++g) {
+            for (uint32_t k = host_group[g]; k < host_group[g + 1]; ++k) acc += len[host_idx[k]];
+            if (acc >= kHostTaskBytes || g + 2 == host_group.size()) { host_task.push_back(uint32_t(g + 1)); acc = 0; }
+        }
+        host_work = h->pool->submit(vit::WorkPool::LOW, host_task.size() - 1, [&](size_t t) {
+            for (uint32_t g = host_task[t]; g < host_task[t + 1]; ++g) {
+                const size_t b = host_group[g], cnt = host_group[g + 1] - b;
+                if (cnt == 1) { const uint64_t i = host_idx[b]; vit::host_object_id(type, data[i], len[i], digests + i * 20); continue; }
+                const uint8_t* ptr[vit::kHostStreams];
+                uint64_t ln[vit::kHostStreams];
+                uint8_t out[20 * vit::kHostStreams];
+                for (size_t j = 0; j < cnt; ++j) { ptr[j] = data[host_idx[b + j]]; ln[j] = len[host_idx[b + j]]; }
+                vit::host_object_ids(type, ptr, ln, cnt, out);
+                for (size_t j = 0; j < cnt; ++j) std::memcpy(digests + host_idx[b + j] * 20, out + 20 * j, 20);
+            }
         });
         h->objects_host += host_idx.size();
         h->bytes_host += host_bytes;

@@ -140,7 +140,7 @@ void plan_host_split(const uint64_t* len, uint64_t n, const SplitRates& r, int q
     std::vector<uint64_t> cand;
     for (uint64_t i = 0; i < n; ++i) {
         total += len[i];
-        if (len[i] >= kHostSplitMin) cand.push_back(i);
+        if (len[i] >= r.min_bytes) cand.push_back(i);
     }
     if (cand.empty()) return;
     // Longest first, equal lengths in index order: a stable LSD radix sort on the
