@@ -25,6 +25,7 @@ while time.time() < t_end:
     h.set_option("sched_tail_percent", int(rng.choice([0, 1, 75])))
     h.set_option("sched_share_below", int(rng.choice([0, 128, 1 << 20])))
     h.set_option("pack_threads", int(rng.choice([3, 8, 16])))
+    h.set_option("host_min_bytes", int(rng.choice([1, 4096, 16384])))   # how short an object the balance may move
     mode = int(rng.integers(0, 3))
     if mode == 0:
         h.set_option("host_auto", 1)
