@@ -336,6 +336,11 @@ bool ObjectStore::ensureHasher()
     // The store's own pool (reads, deflate, writes) keeps the cores busy while a
     // batch is hashed: the hasher's packing threads get a modest share.
     vit_hasher_set_option(hasher_, "pack_threads", uint64_t(std::max(2, io_threads_ / 2)));
+    // Here the host threads are the scarce side (deflate and file operations are
+    // most of a write-tree) and the GPU the idle one: only objects long enough to
+    // hold a GPU lane for milliseconds go to host threads.
+    vit_hasher_set_option(hasher_, "host_min_bytes", 256u << 10);
+    if (const char* e = std::getenv("VIT_HOST_MIN_BYTES")) vit_hasher_set_option(hasher_, "host_min_bytes", std::strtoull(e, nullptr, 10));
     return true;
 }
 
