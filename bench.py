@@ -17,6 +17,7 @@ wait on a CPU barrier, their GPUs idle):
       mixed_slice          a slice of BASELINE configs[3] (lognormal sizes up to 32 MiB) through ONE
                            hasher over all N GPUs of the run (vit_hasher_create(ids, N)): the sharded
                            host path, strong scaling (the slice is the same whatever N)
+      mixed_slice_weak     (N > 1) the same with N times the objects: weak scaling of that path
   cpu_baseline             (N = 1) the reference's hashing loop and its whole write-tree, restated on
                            the host's cores, on bounded samples
 
@@ -109,7 +110,6 @@ def time_host_batch(h, ptrs, sizes, n, runs=3):
 
 
 def end_to_end(args, world, resident_digests):
-    import hashlib
     import torch
     import vit_amd
     from vit_amd import _abi
@@ -132,36 +132,57 @@ def end_to_end(args, world, resident_digests):
     if m > 0:
         visible = max(torch.cuda.device_count(), 1)
         ids = tuple(i % visible for i in range(world))
-        sizes = mixed_sizes(m)
-        buf, offs = fill_host(lib, 0x5EED0004, sizes)
-        ptrs = (offs[:m] + np.uint64(buf.ctypes.data)).astype(np.uint64)
-        payload = int(offs[-1])
-        with vit_amd.Hasher(ids) as h:
-            # 16 host threads per GPU of the run (the CPU share a GPU comes with on the test machines), within the
-            # CPUs this process may run on
-            h.set_option("pack_threads", max(2, min(len(os.sched_getaffinity(0)), 16 * len(ids))))
-            dig, (total_ns, pack_ns, on_gpu, on_host, bytes_host, h2d) = time_host_batch(h, ptrs, sizes, m)
-            rates = {k: h.stat(k) for k in ("lane_rate", "core_rate", "core_rate_multi", "copy_rate", "pack_rate")}
-            threads = h.stat("pool_threads") + (len(ids) if len(ids) > 1 else 1)
-        mv = memoryview(buf)
-        ok = True
-        for i in [0, m - 1, int(np.argmax(sizes))] + np.random.default_rng(3).integers(0, m, 200).tolist():
-            hh = hashlib.sha1(b"blob %d\0" % int(sizes[i]))
-            hh.update(mv[int(offs[i]):int(offs[i + 1])])
-            ok = ok and hh.digest() == dig[i].tobytes()
-        out["mixed_slice"] = {
-            "value": round(payload / total_ns, 3), "unit": "GB/s", "objects_per_s": round(m / (total_ns * 1e-9), 1),
-            "scaling": "strong", "queues": len(ids), "device_ids": list(ids), "objects": m, "payload_bytes": payload,
-            "total_ms": round(total_ns / 1e6, 2), "pack_ms": round(pack_ns / 1e6, 2),
-            "objects_gpu": on_gpu, "objects_host": on_host, "bytes_host": bytes_host, "bytes_h2d": h2d,
-            "host_threads": threads, "measured_rates_bytes_per_s": rates,
-            "bound": "GPU side: %d x PCIe (%.0f GB/s spec each) or the host's DRAM/packing threads, whichever is lower; "
-                     "host side: %d threads x the measured core rate (core_rate_multi where objects outnumber threads: four SHA-1 "
-                     "streams interleaved per core); the two sides run concurrently and add up"
-                     % (len(ids), PCIE_GBS, threads),
-            "workload": "BASELINE configs[3] sizes (lognormal, 15 KB mean, <= 32 MiB), objects above the balance point "
-                        "hashed on host threads meanwhile",
-            "ids_checked_vs_hashlib": 203, "matches": bool(ok)}
+        out["mixed_slice"] = mixed_leg(lib, ids, m, "strong")
+        if world > 1:
+            # the same distribution with N times the objects: per-GPU work as in the one-GPU run, so the fixed
+            # costs of a call (calibration aside: planning, sharding, first chunks) weigh as they do there
+            try:
+                import psutil
+                room = psutil.virtual_memory().available
+            except Exception:
+                room = 0
+            need = 3 * 15000 * m * world
+            if room > need:
+                out["mixed_slice_weak"] = mixed_leg(lib, ids, m * world, "weak")
+            else:
+                out["mixed_slice_weak"] = {"skipped": "host memory: %d bytes available, %d wanted" % (room, need)}
+    return out
+
+
+def mixed_leg(lib, ids, m, scaling):
+    """m objects of BASELINE configs[3]'s size distribution from host memory through ONE hasher over the GPUs `ids`."""
+    import hashlib
+    import vit_amd
+    sizes = mixed_sizes(m)
+    buf, offs = fill_host(lib, 0x5EED0004, sizes, threads=min(64, max(16, 16 * len(ids))))
+    ptrs = (offs[:m] + np.uint64(buf.ctypes.data)).astype(np.uint64)
+    payload = int(offs[-1])
+    with vit_amd.Hasher(ids) as h:
+        # 16 host threads per GPU of the run (the CPU share a GPU comes with on the test machines), within the
+        # CPUs this process may run on
+        h.set_option("pack_threads", max(2, min(len(os.sched_getaffinity(0)), 16 * len(ids))))
+        dig, (total_ns, pack_ns, on_gpu, on_host, bytes_host, h2d) = time_host_batch(h, ptrs, sizes, m)
+        rates = {k: h.stat(k) for k in ("lane_rate", "core_rate", "core_rate_multi", "copy_rate", "pack_rate")}
+        threads = h.stat("pool_threads") + (len(ids) if len(ids) > 1 else 1)
+    mv = memoryview(buf)
+    ok = True
+    for i in [0, m - 1, int(np.argmax(sizes))] + np.random.default_rng(3).integers(0, m, 200).tolist():
+        hh = hashlib.sha1(b"blob %d\0" % int(sizes[i]))
+        hh.update(mv[int(offs[i]):int(offs[i + 1])])
+        ok = ok and hh.digest() == dig[i].tobytes()
+    return {
+        "value": round(payload / total_ns, 3), "unit": "GB/s", "objects_per_s": round(m / (total_ns * 1e-9), 1),
+        "scaling": scaling, "queues": len(ids), "device_ids": list(ids), "objects": m, "payload_bytes": payload,
+        "total_ms": round(total_ns / 1e6, 2), "pack_ms": round(pack_ns / 1e6, 2),
+        "objects_gpu": on_gpu, "objects_host": on_host, "bytes_host": bytes_host, "bytes_h2d": h2d,
+        "host_threads": threads, "measured_rates_bytes_per_s": rates,
+        "bound": "GPU side: %d x PCIe (%.0f GB/s spec each) or the host's DRAM/packing threads, whichever is lower; "
+                 "host side: %d threads x the measured core rate (core_rate_multi where objects outnumber threads: four SHA-1 "
+                 "streams interleaved per core); the two sides run concurrently and add up"
+                 % (len(ids), PCIE_GBS, threads),
+        "workload": "BASELINE configs[3] sizes (lognormal, 15 KB mean, <= 32 MiB), objects above the balance point "
+                    "hashed on host threads meanwhile",
+        "ids_checked_vs_hashlib": 203, "matches": bool(ok)}
     return out
 
 

@@ -123,3 +123,5 @@ def test_bench_runs_as_two_ranks_on_one_gpu():
     m = e["mixed_slice"]
     assert m["queues"] == 2 and m["device_ids"] == [0, 0] and m["matches"] and m["scaling"] == "strong"
     assert m["objects_gpu"] + m["objects_host"] == 30000
+    w = e["mixed_slice_weak"]                             # N times the objects through the same N queues
+    assert w["scaling"] == "weak" and w["queues"] == 2 and w["matches"] and w["objects_gpu"] + w["objects_host"] == 60000
