@@ -131,7 +131,8 @@ int vit_hasher_set_option(vit_hasher *h, const char *name, uint64_t value);
 
 /* Counters since creation: "objects_gpu", "objects_host", "bytes_host",
  * "blocks_gpu", "bytes_h2d", "launches"; of the last call: "last_kernel_ns",
- * "last_pack_ns", "last_total_ns", "last_host_threshold" (shortest length moved to
+ * "last_pack_ns", "last_total_ns", "last_gpu_done_ns", "last_host_done_ns" (when the device queues and the
+ * last host-lane task of the last call had finished, from its start), "last_host_threshold" (shortest length moved to
  * the host threads, less one), "last_host_objects"; the four rates above and
  * "calibrate_ns" (what measuring them cost); "pool_threads", "pool_peak_busy"
  * (most pool threads inside a task at once); and "host_sha_accelerated" (1 when

@@ -129,6 +129,7 @@ def c4(a):
     hash_s = fill_s = 0.0
     payload = checked = 0
     per_slice = []
+    sides = []
     g0, h0, b0 = h.stat("objects_gpu"), h.stat("objects_host"), h.stat("bytes_host")
     for k in range(a.slices):
         first, n = k * per, min(per, a.n - k * per)
@@ -183,6 +184,8 @@ def c4(a):
         hash_s += dt
         payload += int(offs[-1])
         per_slice.append(round(dt, 3))
+        sides.append((round(h.stat("last_gpu_done_ns") / 1e6, 1), round(h.stat("last_host_done_ns") / 1e6, 1),
+                      h.stat("last_host_objects")))
         summary ^= np.bitwise_xor.reduce(dig, axis=0)
         pick = set(np.random.default_rng(k).integers(0, n, 200).tolist()) | {0, n - 1, int(np.argmax(sizes))}
         for i in pick:
@@ -193,7 +196,8 @@ def c4(a):
         del buf
     out.update({"payload_bytes": payload, "hash_seconds": round(hash_s, 3), "fill_seconds": round(fill_s, 1),
                 "GBps": round(payload / hash_s / 1e9, 2), "objects_per_s": round(a.n / hash_s, 1),
-                "per_slice_seconds": per_slice, "objects_gpu": h.stat("objects_gpu") - g0,
+                "per_slice_seconds": per_slice, "per_slice_gpu_done_ms_host_done_ms_host_objects": sides,
+                "objects_gpu": h.stat("objects_gpu") - g0,
                 "objects_host": h.stat("objects_host") - h0, "bytes_host": h.stat("bytes_host") - b0,
                 "last_host_threshold": h.stat("last_host_threshold"), "ids_checked_vs_hashlib": checked,
                 "xor_of_ids": summary.tobytes().hex()})

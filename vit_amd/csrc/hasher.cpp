@@ -75,6 +75,7 @@ struct Queue {
     void*     scratch = nullptr;                           // this DEVICE's address of the kernels' file-scope scratch array
                                                            // (vit_hash_arena_device_static); shared by every queue on the device
     uint64_t  chunks_this_call = 0;
+    bool      grew_this_call = false;                      // a pinned staging arena was (re)allocated during the call
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     void* sort_scratch = nullptr; size_t sort_scratch_bytes = 0;   // vit_bin_order_device
     std::vector<hipEvent_t> timing;                       // pool for vit_time_hash_device
@@ -128,6 +129,8 @@ struct vit_hasher {
     std::atomic<uint64_t> objects_gpu{0}, objects_host{0}, bytes_host{0}, blocks_gpu{0}, bytes_h2d{0}, launches{0};
     uint64_t last_host_threshold = 0, last_host_objects = 0;
     uint64_t last_kernel_ns = 0, last_pack_ns = 0, last_total_ns = 0;
+    uint64_t last_gpu_done_ns = 0;                        // when the device queues of the last call had finished, from its start
+    std::atomic<uint64_t> last_host_done_ns{0};           // ... and when its last host-lane task had
 };
 
 namespace {
@@ -216,6 +219,7 @@ int ensure_arena(Queue& q, Staging& s, uint64_t bytes)
         if (s.h_arena) { HIP_TRYQ(q, hipHostFree(s.h_arena)); s.h_arena = nullptr; s.h_cap = 0; }
         HIP_TRYQ(q, hipHostMalloc(reinterpret_cast<void**>(&s.h_arena), cap, hipHostMallocDefault));
         s.h_cap = cap;
+        q.grew_this_call = true;
     }
     return ensure_device_arena(q, s, bytes);
 }
@@ -448,6 +452,7 @@ int run_queue_body(Queue& q, const Job& job, const std::vector<uint64_t>& mine, 
     q.trace_t0 = clk::now();
     q.trace_log.clear();
     q.chunks_this_call = 0;
+    q.grew_this_call = false;
     if (h->trace) HIP_TRYQ(q, hipEventRecord(q.ev_a, q.stream[0]));
     // One pass over the queue's objects: which are long, and what the rest add up to.
     // Without long objects (the common case) the rest IS the list as given: no copy.
@@ -615,7 +620,8 @@ void calibrate_host(vit_hasher* h)
 //              times 0.8: with four other waves resident, the SIMD's oldest wave
 //              (a long object's wave always is) gets about that share of issue
 //              (1.15 us per block alone, 1.4 to 1.5 us in a full launch).
-int calibrate(vit_hasher* h, const uint8_t* sample, uint64_t sample_len)
+int calibrate(vit_hasher* h, const uint8_t* sample, uint64_t sample_len, const uint8_t* const* data = nullptr,
+              const uint64_t* len_all = nullptr, uint64_t n_all = 0)
 {
     if (h->calibrated) return VIT_OK;
     const auto t0 = clk::now();
@@ -640,6 +646,41 @@ int calibrate(vit_hasher* h, const uint8_t* sample, uint64_t sample_len)
                 best = std::min(best, double(ns_since(t)) * 1e-9);
             }
             h->pack_rate = double(len) / best;
+            // A large batch says more: pack 64 MiB of it (objects of at most 8 MiB) the way a chunk
+            // is packed, on every thread of the budget at once, and take the rate per thread.  One
+            // thread alone on one cold object measures the latency of a single stream of misses, not
+            // what sixteen threads get out of the memory system together.  The 64 MiB before it are
+            // packed first, untimed, into the same stretch of the arena: the first touch of freshly
+            // pinned memory runs at a fraction of the rate (17 against 170 GB/s measured) and is a
+            // cost of the allocation, not of packing.
+            constexpr uint64_t kSample = 64ull << 20, kEach = 8ull << 20;
+            uint64_t next = 0;
+            auto pooled_pack = [&](double* seconds) -> uint64_t {          // returns the payload bytes packed
+                std::vector<uint64_t> pick, prefix(1, 0);
+                uint64_t payload = 0;
+                for (; data && len_all && next < n_all && payload < kSample; ++next) {
+                    if (len_all[next] > kEach || (len_all[next] && !data[next])) continue;
+                    pick.push_back(next);
+                    prefix.push_back(prefix.back() + (4 + 1 + vit::decimal_digits(len_all[next]) + 1 + len_all[next] + 9 + 63) / 64);
+                    payload += len_all[next];
+                }
+                if (payload < kSample / 2 || ensure_arena(q, s, std::max<uint64_t>(prefix.back() * 64, kCopy)) != VIT_OK) return 0;
+                const size_t pieces = std::min<size_t>(pick.size(), size_t(h->pack_threads) * 4);
+                const std::vector<uint64_t> cut = vit::balanced_cuts(pick.size(), int(pieces), prefix.data());
+                const auto t = clk::now();
+                h->pool->run(vit::WorkPool::HIGH, pieces, [&](size_t p) {
+                    for (uint64_t k = cut[p]; k < cut[p + 1]; ++k)
+                        vit::pack_one("blob", 4, data[pick[k]], len_all[pick[k]], s.h_arena + prefix[k] * 64, prefix[k + 1] - prefix[k]);
+                    vit::pack_fence();
+                });
+                *seconds = double(ns_since(t)) * 1e-9;
+                return payload;
+            };
+            double sec = 0;
+            if (h->pack_threads > 1 && pooled_pack(&sec)) {
+                const uint64_t payload = pooled_pack(&sec);
+                if (payload) h->pack_rate = double(payload) / sec / double(h->pack_threads);
+            }
         }
         if (!h->copy_fixed) {
             float best = 1e30f;
@@ -820,6 +861,8 @@ int vit_hasher_get_stat(const vit_hasher* h, const char* name, uint64_t* value)
     else if (k == "last_kernel_ns") *value = h->last_kernel_ns;
     else if (k == "last_pack_ns") *value = h->last_pack_ns;
     else if (k == "last_total_ns") *value = h->last_total_ns;
+    else if (k == "last_gpu_done_ns") *value = h->last_gpu_done_ns;
+    else if (k == "last_host_done_ns") *value = h->last_host_done_ns;
     else if (k == "host_sha_accelerated") *value = vit::HostSha1::accelerated();
     else if (k == "lane_rate") *value = uint64_t(h->lane_rate);
     else if (k == "core_rate") *value = uint64_t(h->core_rate);
@@ -875,7 +918,7 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
         if (any) {
             uint64_t longest = 0;
             for (uint64_t i = 1; i < n; ++i) if (len[i] > len[longest]) longest = i;
-            if (int rc = calibrate(h, data[longest], len[longest])) return rc;
+            if (int rc = calibrate(h, data[longest], len[longest], data, len, n)) return rc;
             vit::plan_host_split(len, n, vit::SplitRates{h->lane_rate, h->core_rate, h->copy_rate, h->pack_rate, h->core_rate_multi, h->host_min_bytes},
                                  int(h->queues.size()), h->pack_threads, host_idx);
             if (!host_idx.empty()) threshold = len[host_idx.back()] - 1;
@@ -959,7 +1002,13 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
             for (uint32_t k = host_group[g]; k < host_group[g + 1]; ++k) acc += len[host_idx[k]];
             if (acc >= kHostTaskBytes || g + 2 == host_group.size()) { host_task.push_back(uint32_t(g + 1)); acc = 0; }
         }
+        h->last_host_done_ns = 0;
         host_work = h->pool->submit(vit::WorkPool::LOW, host_task.size() - 1, [&](size_t t) {
+            struct Stamp {                                // the latest finish over all tasks
+                vit_hasher* h; clk::time_point t0;
+                ~Stamp() { const uint64_t now = ns_since(t0); uint64_t cur = h->last_host_done_ns.load();
+                           while (now > cur && !h->last_host_done_ns.compare_exchange_weak(cur, now)) {} }
+            } stamp{h, t0};
             for (uint32_t g = host_task[t]; g < host_task[t + 1]; ++g) {
                 const size_t b = host_group[g], cnt = host_group[g + 1] - b;
                 if (cnt == 1) { const uint64_t i = host_idx[b]; vit::host_object_id(type, data[i], len[i], digests + i * 20); continue; }
@@ -988,6 +1037,7 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
             workers.t.emplace_back([&, k] { rcs[k] = run_queue(h->queues[k], job, parts[k], &pack_ns[k]); });
         workers.join();
     }
+    h->last_gpu_done_ns = ns_since(t0);
     h->pool->wait(host_work);
     host_work.reset();
     h->last_pack_ns = 0;
@@ -996,7 +1046,11 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
     // DRAM on every thread at once.  Let what this call measured correct the
     // rate the next call balances with: bytes packed over the packing time of
     // the queue that packed longest, per thread of the budget (batches of 256 MiB and more only).
-    if (!h->pack_fixed && h->calibrated && h->last_pack_ns) {
+    // (Not from a call that packed into freshly pinned memory: its first touch runs at a
+    // tenth of the rate and says nothing about the calls to come.)
+    bool fresh_arena = false;
+    for (const Queue& q : h->queues) fresh_arena = fresh_arena || q.grew_this_call;
+    if (!h->pack_fixed && h->calibrated && h->last_pack_ns && !fresh_arena) {
         uint64_t packed = 0;
         for (uint64_t i : gpu_idx) packed += len[i];
         if (packed >= (256ull << 20)) {
