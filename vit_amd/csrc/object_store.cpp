@@ -464,6 +464,7 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
     stats_ = StoreStats();
     const auto t_all = clk::now();
     if (!ensureHasher()) return {};
+    stats_.init_s = since(t_all);                        // the HIP runtime starting up under the first hasher, mostly
 
     std::vector<DirNode> dirs;
     std::vector<FileRec> files;
@@ -552,6 +553,8 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
     if (!ok) return {};
 
     // ---- trees: deepest level first, every directory of a level in one batch
+    const auto t_trees = clk::now();
+    const double blob_hash_s = stats_.hash_s, blob_store_s = stats_.deflate_store_s;
     int max_depth = 0;
     for (const DirNode& d : dirs) max_depth = std::max(max_depth, d.depth);
     for (int depth = max_depth; depth >= 0; --depth) {
@@ -602,6 +605,10 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
                 dirs[level[k]].id[b] = uint8_t(hexNibble(ids[k][2 * b]) * 16 + hexNibble(ids[k][2 * b + 1]));
         stats_.trees += level.size();
     }
+    stats_.trees_s = since(t_trees);
+    stats_.tree_hash_s = stats_.hash_s - blob_hash_s;               // what writeObjects added for the trees
+    stats_.hash_s = blob_hash_s;
+    stats_.deflate_store_s = blob_store_s;
     stats_.total_s = since(t_all);
     return toHex(dirs[root].id, 20);
 }

@@ -37,7 +37,7 @@ struct StoreStats {
     uint64_t skipped = 0;                      // objects already in the store (not deflated or written again)
     // writeTree overlaps its stages: read_s = what the hashing thread waited for file reads, hash_s = GPU batches
     // (pack + copy + kernel + read-back), deflate_store_s = from the first batch's hand-over to the last object on disk
-    double walk_s = 0, read_s = 0, hash_s = 0, deflate_store_s = 0, total_s = 0;
+    double init_s = 0, walk_s = 0, read_s = 0, hash_s = 0, deflate_store_s = 0, trees_s = 0, tree_hash_s = 0, total_s = 0;
 };
 
 class ObjectStore {

@@ -86,8 +86,9 @@ bool cmdWriteTree(int argc, char** argv)
     if (stats) {
         const vit::StoreStats& s = vit::defaultStore().lastStats();
         std::cerr << "blobs " << s.blobs << " trees " << s.trees << " bytes " << s.bytes << " already-stored " << s.skipped
-                  << " | walk " << s.walk_s
+                  << " | init " << s.init_s << " s walk " << s.walk_s
                   << " s read-wait " << s.read_s << " s hash " << s.hash_s << " s blobs-pipeline(read|hash|deflate+store) " << s.deflate_store_s
+                  << " s trees(ids+deflate+store, level by level) " << s.trees_s << " s of which ids " << s.tree_hash_s
                   << " s total " << s.total_s << " s\n";
     }
     return true;
