@@ -104,7 +104,8 @@ def time_host_batch(h, ptrs, sizes, n, runs=3):
         g0, h0, b0, t0 = h.stat("objects_gpu"), h.stat("objects_host"), h.stat("bytes_host"), h.stat("bytes_h2d")
         call()
         rec.append((h.stat("last_total_ns"), h.stat("last_pack_ns"), h.stat("objects_gpu") - g0,
-                    h.stat("objects_host") - h0, h.stat("bytes_host") - b0, h.stat("bytes_h2d") - t0))
+                    h.stat("objects_host") - h0, h.stat("bytes_host") - b0, h.stat("bytes_h2d") - t0,
+                    h.stat("last_plan_ns"), h.stat("last_gpu_done_ns"), h.stat("last_host_done_ns")))
     rec.sort()
     return dig, rec[len(rec) // 2]
 
@@ -121,7 +122,7 @@ def end_to_end(args, world, resident_digests):
     buf, offs = fill_host(lib, SEED, sizes)
     ptrs = (offs[:n] + np.uint64(buf.ctypes.data)).astype(np.uint64)
     with vit_amd.Hasher((0,)) as h:
-        dig, (total_ns, pack_ns, _, _, _, h2d) = time_host_batch(h, ptrs, sizes, n)
+        dig, (total_ns, pack_ns, _, _, _, h2d, *_sides) = time_host_batch(h, ptrs, sizes, n)
         out["uniform_4k"] = {"value": round(n * L / total_ns, 3), "unit": "GB/s", "blobs": n, "queues": 1,
                              "total_ms": round(total_ns / 1e6, 2), "pack_ms": round(pack_ns / 1e6, 2),
                              "bytes_h2d": h2d, "pack_threads": h.stat("pool_threads") + 1,
@@ -161,7 +162,8 @@ def mixed_leg(lib, ids, m, scaling):
         # 16 host threads per GPU of the run (the CPU share a GPU comes with on the test machines), within the
         # CPUs this process may run on
         h.set_option("pack_threads", max(2, min(len(os.sched_getaffinity(0)), 16 * len(ids))))
-        dig, (total_ns, pack_ns, on_gpu, on_host, bytes_host, h2d) = time_host_batch(h, ptrs, sizes, m)
+        dig, (total_ns, pack_ns, on_gpu, on_host, bytes_host, h2d, plan_ns, gpu_done_ns, host_done_ns) = \
+            time_host_batch(h, ptrs, sizes, m)
         rates = {k: h.stat(k) for k in ("lane_rate", "core_rate", "core_rate_multi", "copy_rate", "pack_rate")}
         threads = h.stat("pool_threads") + (len(ids) if len(ids) > 1 else 1)
     mv = memoryview(buf)
@@ -174,6 +176,8 @@ def mixed_leg(lib, ids, m, scaling):
         "value": round(payload / total_ns, 3), "unit": "GB/s", "objects_per_s": round(m / (total_ns * 1e-9), 1),
         "scaling": scaling, "queues": len(ids), "device_ids": list(ids), "objects": m, "payload_bytes": payload,
         "total_ms": round(total_ns / 1e6, 2), "pack_ms": round(pack_ns / 1e6, 2),
+        "plan_ms": round(plan_ns / 1e6, 2), "gpu_side_done_ms": round(gpu_done_ns / 1e6, 2),
+        "host_side_done_ms": round(host_done_ns / 1e6, 2),
         "objects_gpu": on_gpu, "objects_host": on_host, "bytes_host": bytes_host, "bytes_h2d": h2d,
         "host_threads": threads, "measured_rates_bytes_per_s": rates,
         "bound": "GPU side: %d x PCIe (%.0f GB/s spec each) or the host's DRAM/packing threads, whichever is lower; "

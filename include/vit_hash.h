@@ -99,6 +99,11 @@ int vit_hasher_device_count(const vit_hasher *h);
  *                         what "host_auto" balances with.  They are measured on this
  *                         machine the first time a batch needs them (a few ms);
  *                         setting one fixes it, 0 has it measured again
+ *  "host_bias_percent"    the factor (x100) on the host side's estimated time in that balance.
+ *                         The hasher adjusts it after every large call by how much later or
+ *                         earlier than the device queues the host threads finished (the rates
+ *                         are measured one at a time; a batch runs them against one memory
+ *                         system at once); setting it starts the adjustment from there, 0 = 100
  *  "sched_waves"          resident waves per SIMD of the software-scheduled launch that batches in
  *                         binned order (an order array is given, or computed by the library)
  *                         of at least "sched_min_groups" 64-object groups take: a fixed grid
@@ -131,9 +136,10 @@ int vit_hasher_set_option(vit_hasher *h, const char *name, uint64_t value);
 
 /* Counters since creation: "objects_gpu", "objects_host", "bytes_host",
  * "blocks_gpu", "bytes_h2d", "launches"; of the last call: "last_kernel_ns",
- * "last_pack_ns", "last_total_ns", "last_gpu_done_ns", "last_host_done_ns" (when the device queues and the
+ * "last_pack_ns", "last_total_ns", "last_plan_ns" (its serial preamble: the host/GPU split, block counts, sharding),
+ * "last_gpu_done_ns", "last_host_done_ns" (when the device queues and the
  * last host-lane task of the last call had finished, from its start), "last_host_threshold" (shortest length moved to
- * the host threads, less one), "last_host_objects"; the four rates above and
+ * the host threads, less one), "last_host_objects"; "host_bias_percent"; the four rates above and
  * "calibrate_ns" (what measuring them cost); "pool_threads", "pool_peak_busy"
  * (most pool threads inside a task at once); and "host_sha_accelerated" (1 when
  * the host lane uses the CPU's SHA extensions). */

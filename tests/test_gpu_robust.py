@@ -135,6 +135,37 @@ def test_uniform_batch_of_large_objects_is_shared_not_dumped_on_the_host(hasher)
             hasher.set_option(k, 0)
 
 
+def test_balance_learns_from_when_the_two_sides_finish(hasher):
+    """The host cores believed 2.5 times as fast as they are: the first call leaves the host threads working long
+    after the device queues are done; the factor the hasher keeps on the host side's estimate then grows call by
+    call until the two sides finish together again.  Ids never change."""
+    import vit_amd
+    rng = np.random.default_rng(21)
+    n = 60_000
+    lens = np.minimum(np.exp(rng.normal(np.log(30000.0), 1.0, n)), 4 << 20).astype(np.uint64)     # 3 GB, half of it >= 16 KiB objects
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    buf = np.frombuffer(vit_amd.synth_bytes(77, 0, 8 << 20), dtype=np.uint8)
+    buf = np.tile(buf, int(offs[-1]) // len(buf) + 1)
+    blobs = [buf[int(offs[i]):int(offs[i + 1])] for i in range(n)]
+    want = hasher.hash_blobs(blobs)                                   # calibrates; staging memory pinned
+    hasher.hash_blobs(blobs)
+    rates = {k: hasher.stat(k) for k in ("lane_rate", "core_rate", "core_rate_multi", "copy_rate", "pack_rate")}
+    try:
+        for k, v in rates.items():
+            hasher.set_option(k, int(v * 2.5) if k.startswith("core") else v)
+        hasher.set_option("host_bias_percent", 100)
+        ratios = []
+        for _ in range(7):
+            assert (hasher.hash_blobs(blobs) == want).all()
+            ratios.append(hasher.stat("last_host_done_ns") / hasher.stat("last_gpu_done_ns"))
+        print("host done / gpu done per call:", [round(r, 2) for r in ratios], "bias", hasher.stat("host_bias_percent"))
+        assert ratios[0] > 1.3 and 0.7 < sorted(ratios[-3:])[1] < 1.3 and hasher.stat("host_bias_percent") > 125, ratios
+    finally:
+        for k in rates:
+            hasher.set_option(k, 0)
+        hasher.set_option("host_bias_percent", 100)
+
+
 def _threads_now():
     return len(os.listdir("/proc/self/task"))
 

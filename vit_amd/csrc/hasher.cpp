@@ -25,8 +25,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -124,11 +126,13 @@ struct vit_hasher {
     double core_rate_multi = 0;                           // one core, kHostStreams objects interleaved (sha1_host.h); <= core_rate: not used
     bool lane_fixed = false, core_fixed = false, copy_fixed = false, pack_fixed = false, core_multi_fixed = false;
     bool calibrated = false, host_calibrated = false;
+    double host_bias = 1;                                 // see the end of hash_batch
     uint64_t calibrate_ns = 0;
     uint64_t fail_at_chunk = 0;                           // fault injection for tests: 0 = off
     std::atomic<uint64_t> objects_gpu{0}, objects_host{0}, bytes_host{0}, blocks_gpu{0}, bytes_h2d{0}, launches{0};
     uint64_t last_host_threshold = 0, last_host_objects = 0;
     uint64_t last_kernel_ns = 0, last_pack_ns = 0, last_total_ns = 0;
+    uint64_t last_plan_ns = 0;                            // the last call's serial preamble: split plan, block counts, sharding
     uint64_t last_gpu_done_ns = 0;                        // when the device queues of the last call had finished, from its start
     std::atomic<uint64_t> last_host_done_ns{0};           // ... and when its last host-lane task had
 };
@@ -540,20 +544,36 @@ void shard(const std::vector<uint64_t>& idx, const uint32_t* nb, size_t nq, std:
     uint64_t total = 0;
     for (uint64_t i : idx) total += nb[i];
     const uint64_t fair = total / nq + 1, big = fair / 4 + 1;
-    std::vector<uint64_t> load(nq, 0), large, small;
-    for (uint64_t i : idx) (nb[i] >= big ? large : small).push_back(i);
+    std::vector<uint64_t> load(nq, 0), large;
+    for (uint64_t i : idx) if (nb[i] >= big) large.push_back(i);
+    for (auto& v : out) v.reserve(idx.size() / nq + idx.size() / (8 * nq) + 16);
     std::stable_sort(large.begin(), large.end(), [&](uint64_t a, uint64_t b) { return nb[a] > nb[b]; });
     for (uint64_t i : large) {
         size_t best = 0;
         for (size_t k = 1; k < nq; ++k) if (load[k] < load[best]) best = k;
         out[best].push_back(i); load[best] += nb[i];
     }
+    std::vector<size_t> n_large(nq);
+    for (size_t q = 0; q < nq; ++q) n_large[q] = out[q].size();
     size_t k = 0;
-    for (uint64_t i : small) {
+    for (uint64_t i : idx) {
+        if (nb[i] >= big) continue;
         while (k + 1 < nq && load[k] >= fair) ++k;
         out[k].push_back(i); load[k] += nb[i];
     }
-    for (auto& v : out) std::sort(v.begin(), v.end());
+    // Every queue's list in index order.  The small objects arrived in the order
+    // of idx (ascending, as the callers pass it): sort the few large ones and
+    // merge, which is linear; a million-object list costs a full sort 20 ms.
+    for (size_t q = 0; q < nq; ++q) {
+        auto& v = out[q];
+        const auto mid = v.begin() + long(n_large[q]);
+        if (std::is_sorted(mid, v.end())) {
+            std::sort(v.begin(), mid);
+            std::inplace_merge(v.begin(), mid, v.end());
+        } else {
+            std::sort(v.begin(), v.end());
+        }
+    }
 }
 
 // Read the queue's device status word, and the one in the device's static
@@ -836,6 +856,7 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     else if (k == "core_rate_multi") rate(h->core_rate_multi, h->core_multi_fixed);
     else if (k == "copy_rate") rate(h->copy_rate, h->copy_fixed);
     else if (k == "pack_rate") rate(h->pack_rate, h->pack_fixed);
+    else if (k == "host_bias_percent") h->host_bias = value ? double(value) / 100.0 : 1.0;
     else if (k == "debug_fail_at_chunk") h->fail_at_chunk = value;
     else if (k == "sched_waves") h->sched_waves = uint32_t(value > 8 ? 8 : value);
     else if (k == "sched_share_below") h->sched_share_below = uint32_t(value > 0xFFFFFFFEull ? 0xFFFFFFFEu : value);
@@ -862,6 +883,8 @@ int vit_hasher_get_stat(const vit_hasher* h, const char* name, uint64_t* value)
     else if (k == "last_pack_ns") *value = h->last_pack_ns;
     else if (k == "last_total_ns") *value = h->last_total_ns;
     else if (k == "last_gpu_done_ns") *value = h->last_gpu_done_ns;
+    else if (k == "last_plan_ns") *value = h->last_plan_ns;
+    else if (k == "host_bias_percent") *value = uint64_t(h->host_bias * 100.0 + 0.5);
     else if (k == "last_host_done_ns") *value = h->last_host_done_ns;
     else if (k == "host_sha_accelerated") *value = vit::HostSha1::accelerated();
     else if (k == "lane_rate") *value = uint64_t(h->lane_rate);
@@ -919,7 +942,7 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
             uint64_t longest = 0;
             for (uint64_t i = 1; i < n; ++i) if (len[i] > len[longest]) longest = i;
             if (int rc = calibrate(h, data[longest], len[longest], data, len, n)) return rc;
-            vit::plan_host_split(len, n, vit::SplitRates{h->lane_rate, h->core_rate, h->copy_rate, h->pack_rate, h->core_rate_multi, h->host_min_bytes},
+            vit::plan_host_split(len, n, vit::SplitRates{h->lane_rate, h->core_rate, h->copy_rate, h->pack_rate, h->core_rate_multi, h->host_min_bytes, h->host_bias},
                                  int(h->queues.size()), h->pack_threads, host_idx);
             if (!host_idx.empty()) threshold = len[host_idx.back()] - 1;
         }
@@ -1029,6 +1052,7 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
     shard(gpu_idx, nb.data(), h->queues.size(), parts);
     std::vector<int> rcs(h->queues.size(), VIT_OK);
     std::vector<uint64_t> pack_ns(h->queues.size(), 0);
+    h->last_plan_ns = ns_since(t0);
     if (h->queues.size() == 1) {
         rcs[0] = run_queue(h->queues[0], job, parts[0], &pack_ns[0]);
     } else {
@@ -1057,6 +1081,17 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
             const double per_thread = double(packed) / (double(h->last_pack_ns) * 1e-9) / double(h->pack_threads);
             h->pack_rate = 0.5 * h->pack_rate + 0.5 * per_thread;
         }
+    }
+    // The rates are measured one at a time on an idle machine; a batch runs them
+    // all at once against one memory system, and the more GPUs a hasher drives the
+    // less of the sum the host's DRAM delivers.  What the model cannot know it
+    // learns: the host side's estimate is scaled by how much later (or earlier)
+    // than the device queues the host threads finished, damped, and only from
+    // calls in which both sides had real work spread over many objects.
+    if (h->host_policy == 1 && !fresh_arena && host_idx.size() >= 4 * size_t(h->pack_threads) &&
+        gpu_idx.size() >= 1024 && h->last_gpu_done_ns > 1000000 && h->last_host_done_ns > 1000000) {
+        const double ratio = std::min(2.0, std::max(0.5, double(h->last_host_done_ns.load()) / double(h->last_gpu_done_ns)));
+        h->host_bias = std::min(5.0, std::max(0.2, h->host_bias * std::pow(ratio, 0.7)));
     }
     h->last_total_ns = ns_since(t0);
     if (h->trace)

@@ -136,50 +136,58 @@ void plan_host_split(const uint64_t* len, uint64_t n, const SplitRates& r, int q
 {
     out.clear();
     if (!(r.lane > 0) || !(r.core > 0) || !(r.copy > 0) || !(r.pack > 0) || queues < 1 || threads < 1) return;
-    uint64_t total = 0;
-    std::vector<uint64_t> cand;
+    // Candidates as (length, index) pairs, so that the sort below streams through
+    // memory instead of looking every length up by index.
+    struct Cand { uint64_t len, idx; };
+    uint64_t total = 0, maxlen = 0;
+    std::vector<Cand> cand;
+    cand.reserve(size_t(n / 8 + 16));
     for (uint64_t i = 0; i < n; ++i) {
         total += len[i];
-        if (len[i] >= r.min_bytes) cand.push_back(i);
+        if (len[i] >= r.min_bytes) { cand.push_back(Cand{len[i], i}); maxlen = std::max(maxlen, len[i]); }
     }
     if (cand.empty()) return;
     // Longest first, equal lengths in index order: a stable LSD radix sort on the
     // lengths (a slice of a large repository has hundreds of thousands of
     // candidates per call; a comparison sort of them costs more than the hashing
-    // of a chunk).
+    // of a chunk).  All digit histograms come from one pass.
     {
-        uint64_t maxlen = 0;
-        for (uint64_t i : cand) maxlen = std::max(maxlen, len[i]);
-        std::vector<uint64_t> tmp(cand.size());
-        uint64_t* src = cand.data();
-        uint64_t* dst = tmp.data();
-        for (int shift = 0; shift < 64 && (maxlen >> shift); shift += 11) {
-            size_t count[2049] = {0};
-            for (size_t k = 0; k < cand.size(); ++k) ++count[(2047u - ((len[src[k]] >> shift) & 2047u)) + 1];
-            for (int d = 0; d < 2048; ++d) count[d + 1] += count[d];
-            for (size_t k = 0; k < cand.size(); ++k) dst[count[2047u - ((len[src[k]] >> shift) & 2047u)]++] = src[k];
+        constexpr int kBits = 11, kDigits = 1 << kBits;
+        int passes = 0;
+        while (passes * kBits < 64 && (maxlen >> (passes * kBits))) ++passes;
+        std::vector<size_t> count(size_t(passes) * (kDigits + 1), 0);
+        for (const Cand& c : cand)
+            for (int p = 0; p < passes; ++p) ++count[size_t(p) * (kDigits + 1) + (kDigits - 1 - ((c.len >> (p * kBits)) & (kDigits - 1))) + 1];
+        std::vector<Cand> tmp(cand.size());
+        Cand* src = cand.data();
+        Cand* dst = tmp.data();
+        for (int p = 0; p < passes; ++p) {
+            size_t* cnt = &count[size_t(p) * (kDigits + 1)];
+            for (int d = 0; d < kDigits; ++d) cnt[d + 1] += cnt[d];
+            for (size_t k = 0; k < cand.size(); ++k) dst[cnt[kDigits - 1 - ((src[k].len >> (p * kBits)) & (kDigits - 1))]++] = src[k];
             std::swap(src, dst);
         }
-        if (src != cand.data()) std::memcpy(cand.data(), src, cand.size() * sizeof(uint64_t));
+        if (src != cand.data()) std::memcpy(cand.data(), src, cand.size() * sizeof(Cand));
     }
     const double nt = double(threads);
     const double queue_rate = std::min(0.8 * r.copy * double(queues), r.pack * nt);
-    const double longest = double(len[cand[0]]);
+    const double longest = double(cand[0].len);
     double gpu_bytes = double(total), host_bytes = 0;
     size_t moved = 0;
-    for (uint64_t i : cand) {
-        const double L = double(len[i]);
+    for (const Cand& c : cand) {
+        const double L = double(c.len);
         const double gpu_time = std::max(gpu_bytes / queue_rate, L / r.lane);
         // streams a core would run side by side with this many objects moved: 1 .. 4
         const double per_thread = double(moved + 1) / nt;
         const double streams = per_thread < 1 ? 1 : (per_thread > 4 ? 4 : per_thread);
         const double core_eff = r.core_multi > r.core ? r.core + (r.core_multi - r.core) * (streams - 1) / 3 : r.core;
-        const double host_time = std::max(((host_bytes + L) / core_eff + (gpu_bytes - L) / r.pack) / nt, longest / r.core);
+        const double host_time = std::max(r.host_bias * ((host_bytes + L) / core_eff + (gpu_bytes - L) / r.pack) / nt, longest / r.core);
         if (host_time >= gpu_time) break;
         gpu_bytes -= L; host_bytes += L;
         ++moved;
     }
-    out.assign(cand.begin(), cand.begin() + long(moved));
+    out.resize(moved);
+    for (size_t k = 0; k < moved; ++k) out[k] = cand[k].idx;
 }
 
 static inline uint64_t mix64(uint64_t z)

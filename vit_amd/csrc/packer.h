@@ -38,7 +38,9 @@ bool bin_order(const uint32_t* nblocks, uint64_t n, uint32_t* order);
 // in proportion to the moved objects per thread (one object per thread: `core`,
 // four or more: `core_multi`).
 // min_bytes: objects shorter than this never move (default kHostSplitMin).
-struct SplitRates { double lane, core, copy, pack; double core_multi = 0; uint64_t min_bytes = 16u << 10; };
+// host_bias: factor on the host side's estimated time (1 = the model as it is; the hasher learns
+// it from when the two sides of its earlier calls finished).
+struct SplitRates { double lane, core, copy, pack; double core_multi = 0; uint64_t min_bytes = 16u << 10; double host_bias = 1; };
 constexpr uint64_t kHostSplitMin = 16u << 10;
 void plan_host_split(const uint64_t* len, uint64_t n, const SplitRates& r, int queues, int threads,
                      std::vector<uint64_t>& out);
