@@ -178,6 +178,8 @@ def mixed_leg(lib, ids, m, scaling):
         "total_ms": round(total_ns / 1e6, 2), "pack_ms": round(pack_ns / 1e6, 2),
         "plan_ms": round(plan_ns / 1e6, 2), "gpu_side_done_ms": round(gpu_done_ns / 1e6, 2),
         "host_side_done_ms": round(host_done_ns / 1e6, 2),
+        "gpu_side_GBps": round((payload - bytes_host) / max(gpu_done_ns, 1), 2),
+        "host_side_GBps": round(bytes_host / max(host_done_ns, 1), 2),
         "objects_gpu": on_gpu, "objects_host": on_host, "bytes_host": bytes_host, "bytes_h2d": h2d,
         "host_threads": threads, "measured_rates_bytes_per_s": rates,
         "bound": "GPU side: %d x PCIe (%.0f GB/s spec each) or the host's DRAM/packing threads, whichever is lower; "
