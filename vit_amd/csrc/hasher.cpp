@@ -940,10 +940,13 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
         for (uint64_t i = 0; i < n && !any; ++i) any = len[i] >= h->host_min_bytes;
         if (any) {
             uint64_t longest = 0;
-            for (uint64_t i = 1; i < n; ++i) if (len[i] > len[longest]) longest = i;
+            if (!h->calibrated) for (uint64_t i = 1; i < n; ++i) if (len[i] > len[longest]) longest = i;   // calibration's sample
             if (int rc = calibrate(h, data[longest], len[longest], data, len, n)) return rc;
+            const vit::ParallelFor on_pool = [h](size_t parts, const std::function<void(size_t)>& fn) {
+                h->pool->run(vit::WorkPool::HIGH, parts, fn);
+            };
             vit::plan_host_split(len, n, vit::SplitRates{h->lane_rate, h->core_rate, h->copy_rate, h->pack_rate, h->core_rate_multi, h->host_min_bytes, h->host_bias},
-                                 int(h->queues.size()), h->pack_threads, host_idx);
+                                 int(h->queues.size()), h->pack_threads, host_idx, &on_pool);
             if (!host_idx.empty()) threshold = len[host_idx.back()] - 1;
         }
     }

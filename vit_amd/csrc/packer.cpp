@@ -132,7 +132,7 @@ bool bin_order(const uint32_t* nblocks, uint64_t n, uint32_t* order)
 }
 
 void plan_host_split(const uint64_t* len, uint64_t n, const SplitRates& r, int queues, int threads,
-                     std::vector<uint64_t>& out)
+                     std::vector<uint64_t>& out, const ParallelFor* parallel_for)
 {
     out.clear();
     if (!(r.lane > 0) || !(r.core > 0) || !(r.copy > 0) || !(r.pack > 0) || queues < 1 || threads < 1) return;
@@ -141,10 +141,29 @@ void plan_host_split(const uint64_t* len, uint64_t n, const SplitRates& r, int q
     struct Cand { uint64_t len, idx; };
     uint64_t total = 0, maxlen = 0;
     std::vector<Cand> cand;
-    cand.reserve(size_t(n / 8 + 16));
-    for (uint64_t i = 0; i < n; ++i) {
-        total += len[i];
-        if (len[i] >= r.min_bytes) { cand.push_back(Cand{len[i], i}); maxlen = std::max(maxlen, len[i]); }
+    if (parallel_for && n >= (1u << 18)) {
+        // parts in index order, each with its own list; joined in that order, the
+        // candidates are in index order as the serial scan leaves them
+        constexpr size_t kParts = 64;
+        struct Part { std::vector<Cand> c; uint64_t total = 0, maxlen = 0; };
+        std::vector<Part> part(kParts);
+        (*parallel_for)(kParts, [&](size_t p) {
+            Part& me = part[p];
+            for (uint64_t i = n * p / kParts; i < n * (p + 1) / kParts; ++i) {
+                me.total += len[i];
+                if (len[i] >= r.min_bytes) { me.c.push_back(Cand{len[i], i}); me.maxlen = std::max(me.maxlen, len[i]); }
+            }
+        });
+        size_t count = 0;
+        for (const Part& p : part) { count += p.c.size(); total += p.total; maxlen = std::max(maxlen, p.maxlen); }
+        cand.reserve(count);
+        for (const Part& p : part) cand.insert(cand.end(), p.c.begin(), p.c.end());
+    } else {
+        cand.reserve(size_t(n / 8 + 16));
+        for (uint64_t i = 0; i < n; ++i) {
+            total += len[i];
+            if (len[i] >= r.min_bytes) { cand.push_back(Cand{len[i], i}); maxlen = std::max(maxlen, len[i]); }
+        }
     }
     if (cand.empty()) return;
     // Longest first, equal lengths in index order: a stable LSD radix sort on the

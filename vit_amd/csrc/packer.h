@@ -1,6 +1,7 @@
 // packer.h — host-side arena packing primitives (see packer.cpp).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <vector>
 
 namespace vit {
@@ -42,7 +43,10 @@ bool bin_order(const uint32_t* nblocks, uint64_t n, uint32_t* order);
 // it from when the two sides of its earlier calls finished).
 struct SplitRates { double lane, core, copy, pack; double core_multi = 0; uint64_t min_bytes = 16u << 10; double host_bias = 1; };
 constexpr uint64_t kHostSplitMin = 16u << 10;
+// parallel_for (optional): runs fn(0) .. fn(parts - 1) on the caller's threads and returns when all have; the
+// scan of a large batch for candidates is cut into parts with it.
+using ParallelFor = std::function<void(size_t parts, const std::function<void(size_t)>& fn)>;
 void plan_host_split(const uint64_t* len, uint64_t n, const SplitRates& r, int queues, int threads,
-                     std::vector<uint64_t>& out);
+                     std::vector<uint64_t>& out, const ParallelFor* parallel_for = nullptr);
 
 }  // namespace vit
