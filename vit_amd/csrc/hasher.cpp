@@ -698,7 +698,8 @@ int calibrate(vit_hasher* h, const uint8_t* sample, uint64_t sample_len, const u
             };
             double sec = 0;
             if (h->pack_threads > 1 && pooled_pack(&sec)) {
-                const uint64_t payload = pooled_pack(&sec);
+                uint64_t payload = pooled_pack(&sec);
+                if (!payload) { next = 0; payload = pooled_pack(&sec); }      // a batch of under 128 MiB: the same stretch again
                 if (payload) h->pack_rate = double(payload) / sec / double(h->pack_threads);
             }
         }
@@ -927,6 +928,8 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
     const auto t0 = clk::now();
     VIT_NOEXCEPT_BEGIN
     for (Queue& q : h->queues) { drain(q); q.status_seen = 0; }
+    h->last_host_done_ns = 0;
+    h->last_gpu_done_ns = 0;
 
     // Which objects leave the GPU for host threads: a fixed threshold, or (auto)
     // the balance vit::plan_host_split strikes with the rates measured on this
@@ -1028,7 +1031,6 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
             for (uint32_t k = host_group[g]; k < host_group[g + 1]; ++k) acc += len[host_idx[k]];
             if (acc >= kHostTaskBytes || g + 2 == host_group.size()) { host_task.push_back(uint32_t(g + 1)); acc = 0; }
         }
-        h->last_host_done_ns = 0;
         host_work = h->pool->submit(vit::WorkPool::LOW, host_task.size() - 1, [&](size_t t) {
             struct Stamp {                                // the latest finish over all tasks
                 vit_hasher* h; clk::time_point t0;
