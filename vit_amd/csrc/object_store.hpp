@@ -98,6 +98,7 @@ public:
 private:
     struct StoreOutcome { std::atomic<int> failed{0}; std::atomic<uint64_t> skipped{0}; };   // 1 compression, 2 write
     bool ensureHasher();
+    void tuneHasher();                                   // per call: which objects may leave the GPU for host threads
     WorkPool& pool();
     WorkPool::Ticket storeAsync(const std::string& type, const std::vector<std::string>& contents,
                                 const std::vector<uint8_t>& raw, StoreOutcome& outcome);
