@@ -181,6 +181,16 @@ int vit_sha1_buffers(vit_hasher *h, const uint8_t *const *data, const uint64_t *
  * Same result as the SHA1() at reference src/commit.cpp:93-94. */
 int vit_host_object_id(const char *type, const uint8_t *data, uint64_t len, uint8_t *digest);
 
+/* ids of n objects on the calling host thread, up to four of them at a time with
+ * their SHA-1 block functions interleaved (one stream's rounds are a dependent
+ * chain; a core with pipelined SHA instructions gets through more than twice the
+ * bytes that way).  The routine the scheduler applies to host-lane objects that
+ * outnumber the threads; exported so that path can be checked on its own.
+ * digests: n x 20 bytes, in input order.  Same results as n calls of
+ * vit_host_object_id, i.e. as the SHA1() at reference src/commit.cpp:93-94. */
+int vit_host_object_ids(const char *type, const uint8_t *const *data, const uint64_t *len, uint64_t n,
+                        uint8_t *digests);
+
 /* ---- pre-packed arenas ---------------------------------------------------- */
 
 /* Pinned host memory for arenas (hipHostMalloc); free with vit_arena_free. */

@@ -241,6 +241,34 @@ def test_host_lane_sha1_matches_reference_golden(lib, oracle, golden_objects):
     assert lib.vit_host_object_id(b"blob", None, 5, out) == -1
 
 
+def test_interleaved_host_lane_matches_reference_golden(lib, oracle, golden_objects):
+    """vit_host_object_ids (several objects' SHA-1 streams side by side on one core) on the 256 golden blob lengths,
+    in input order and in groups whose members differ in length by orders of magnitude, and on typed objects."""
+    g = golden_objects["blobs"]
+    ids = g["ids"]
+    for order in (list(range(len(ids))), list(range(len(ids) - 1, -1, -1)),
+                  np.random.default_rng(4).permutation(len(ids)).tolist()):
+        bufs = [np.frombuffer(oracle.synth_bytes(g["seed"], ids[i][0], ids[i][0]) or b"\0", dtype=np.uint8) for i in order]
+        lens = np.array([ids[i][0] for i in order], dtype=np.uint64)
+        ptrs = (C.c_void_p * len(order))(*[b.ctypes.data if L else None for b, L in zip(bufs, lens)])
+        out = np.zeros((len(order), 20), dtype=np.uint8)
+        assert lib.vit_host_object_ids(b"blob", ptrs, lens.ctypes.data, len(order), out.ctypes.data) == 0
+        for k, i in enumerate(order):
+            assert out[k].tobytes().hex() == ids[i][1], (ids[i][0], k)
+    for n in (0, 1, 2, 3, 5):                                     # counts around the group size; another type
+        data = [oracle.synth_bytes(9, i, 1000 * i + i) for i in range(n)]
+        bufs = [np.frombuffer(d or b"\0", dtype=np.uint8) for d in data]
+        lens = np.array([len(d) for d in data], dtype=np.uint64)
+        ptrs = (C.c_void_p * max(n, 1))(*[b.ctypes.data if len(d) else None for b, d in zip(bufs, data)])
+        out = np.zeros((max(n, 1), 20), dtype=np.uint8)
+        assert lib.vit_host_object_ids(b"commit", ptrs, lens.ctypes.data, n, out.ctypes.data) == 0
+        for i in range(n):
+            assert out[i].tobytes() == oracle.object_id("commit", data[i])
+    one = (C.c_void_p * 1)(None)
+    five = np.array([5], dtype=np.uint64)
+    assert lib.vit_host_object_ids(b"blob", one, five.ctypes.data, 1, out.ctypes.data) == -1
+
+
 def test_library_synth_bytes_is_the_shared_generator(oracle):
     import vit_amd
     for L in (0, 1, 8, 9, 4096, 4099):

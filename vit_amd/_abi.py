@@ -33,6 +33,7 @@ SIGNATURES = {
     "vit_hash_blobs": (C.c_int, [vp, vp, vp, C.c_uint64, vp]),
     "vit_sha1_buffers": (C.c_int, [vp, vp, vp, C.c_uint64, vp]),
     "vit_host_object_id": (C.c_int, [C.c_char_p, vp, C.c_uint64, vp]),
+    "vit_host_object_ids": (C.c_int, [C.c_char_p, vp, vp, C.c_uint64, vp]),
     "vit_arena_alloc": (C.c_int, [vp, C.c_uint64, C.POINTER(vp)]),
     "vit_arena_free": (C.c_int, [vp, vp]),
     "vit_arena_pack": (C.c_int, [C.c_char_p, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp, u64p, C.c_int]),

@@ -1133,6 +1133,14 @@ int vit_host_object_id(const char* type, const uint8_t* data, uint64_t len, uint
     return VIT_OK;
 }
 
+int vit_host_object_ids(const char* type, const uint8_t* const* data, const uint64_t* len, uint64_t n, uint8_t* digests)
+{
+    if (!vit::type_len_checked(type) || (n && (!data || !len || !digests))) return VIT_ERR_ARG;
+    for (uint64_t i = 0; i < n; ++i) if (len[i] && !data[i]) return VIT_ERR_ARG;
+    vit::host_object_ids(type, data, len, size_t(n), digests);
+    return VIT_OK;
+}
+
 int vit_shard_plan(const uint32_t* nblocks, uint64_t n, int n_queues, uint32_t* queue_of)
 {
     if (n_queues < 1 || (n && (!nblocks || !queue_of))) return VIT_ERR_ARG;
