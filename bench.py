@@ -117,7 +117,7 @@ def end_to_end(args, world, resident_digests):
     lib = _abi.load()
     out = {"note": "time inside vit_hash_blobs (pack + H2D + kernel + D2H); PCIe-bound, never reported as value",
            "pcie_spec_GBps_per_gpu": PCIE_GBS}
-    n, L = min(args.blobs, 262144), args.blob_len
+    n, L = min(args.blobs, 524288), args.blob_len
     sizes = np.full(n, L, dtype=np.uint64)
     buf, offs = fill_host(lib, SEED, sizes)
     ptrs = (offs[:n] + np.uint64(buf.ctypes.data)).astype(np.uint64)
