@@ -14,6 +14,7 @@ rng = np.random.default_rng(seed)
 pool = np.frombuffer(vit_amd.synth_bytes(99, seed, 64 << 20), dtype=np.uint8)
 hashers = [vit_amd.Hasher((0,)), vit_amd.Hasher((0, 0))]
 t_end = time.time() + seconds
+t_say = time.time() + 30
 batches = objects = nbytes = 0
 while time.time() < t_end:
     h = hashers[int(rng.integers(0, 2))]
@@ -60,6 +61,9 @@ while time.time() < t_end:
             print(json.dumps({"mismatch": True, "batch": batches, "object": int(i), "len": len(b), "raw": raw, "n": n}))
             sys.exit(1)
     batches += 1; objects += n; nbytes += int(lens.sum())
+    if time.time() > t_say:                                # a long silent run looks hung to whoever watches it
+        print("... %d batches, %d objects, no mismatch" % (batches, objects), file=sys.stderr, flush=True)
+        t_say = time.time() + 30
     if batches % 7 == 0:                                   # a device-resident batch: plain launch against the static-scratch launch
         m = int(rng.choice([1, 65, 3000, 200000]))
         dl = np.minimum(np.exp(rng.normal(np.log(900.0), 1.7, m)), 150000).astype(np.uint64)
