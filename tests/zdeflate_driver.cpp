@@ -1,0 +1,52 @@
+// The deflate restatement of vit_amd/csrc/zdeflate.h against the zlib library itself (compress2 at the default
+// level, which is what the reference's compress() call at src/commit.cpp:100 runs): random, text-like, constant,
+// long-distance and short-distance repetitive inputs of every size up to the 64 KiB the restatement covers, byte
+// for byte.  Built and run by tests/test_zdeflate.py:  zdeflate_driver <inputs> <seed>
+#include "zdeflate.h"
+#include <zlib.h>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+#include <string>
+struct PtrIn { const uint8_t* p; uint8_t operator()(uint32_t i) const { return p[i]; } };
+int main(int argc, char** argv) {
+    int rounds = argc > 1 ? atoi(argv[1]) : 2000;
+    zd::Tables t; zd::make_tables(t);
+    std::vector<uint16_t> head(zd::kHashSize), prev(32768), dbuf(zd::kLitBufSize);
+    std::vector<uint8_t> lbuf(zd::kLitBufSize);
+    std::mt19937_64 rng(atoi(argc > 2 ? argv[2] : "777"));
+    static zd::Deflater<PtrIn> d;
+    int bad = 0; size_t total = 0;
+    const char* words[] = {"the ", "quick ", "brown ", "fox ", "int ", "return ", "void ", "#include ", "\n", "    ", "for (", "i++) {", "}", "const ", "0x", "==", "abcabcabc"};
+    for (int r = 0; r < rounds; ++r) {
+        uint32_t n;
+        switch (rng() % 8) { case 0: n = rng() % 40; break; case 1: n = rng() % 700; break; case 2: n = 4000 + rng() % 300; break;
+            case 3: n = 16000 + rng() % 1000; break; case 4: n = 32700 + rng() % 200; break; case 5: n = 65536 - rng() % 3; break; default: n = rng() % 65537; }
+        std::vector<uint8_t> in(n + 1);
+        int kind = rng() % 7;
+        if (kind == 0) for (auto& b : in) b = uint8_t(rng());
+        else if (kind == 1) for (auto& b : in) b = uint8_t(rng() % 4 + 'a');
+        else if (kind == 2) { size_t k = 0; while (k < n) { const char* w = words[rng() % 17]; size_t l = strlen(w); for (size_t j = 0; j < l && k < n; ++j) in[k++] = uint8_t(w[j]); } }
+        else if (kind == 3) { uint8_t v = uint8_t(rng()); for (auto& b : in) b = v; }
+        else if (kind == 4) { for (size_t k = 0; k < n; ++k) in[k] = (k >= 5000 && rng() % 10) ? in[k - 5000 + (rng() % 3 == 0)] : uint8_t(rng()); }
+        else if (kind == 5) { for (size_t k = 0; k < n; ++k) in[k] = (k >= 40 && rng() % 50) ? in[k - 1 - rng() % 40] : uint8_t(rng() % 7); }
+        else { for (size_t k = 0; k < n; ++k) in[k] = uint8_t((k * 7 + (k >> 8)) ^ (rng() % 64 == 0 ? rng() : 0)); }
+        uLongf zl = compressBound(n);
+        std::vector<uint8_t> z(zl);
+        if (compress2(z.data(), &zl, in.data(), n, 6) != Z_OK) { puts("zlib failed"); return 2; }
+        std::fill(head.begin(), head.end(), 0);
+        std::vector<uint8_t> out(zd::bound(n));
+        zd::Work w{head.data(), prev.data(), dbuf.data(), lbuf.data(), out.data(), uint32_t(out.size())};
+        d.in = PtrIn{in.data()};
+        uint32_t got = d.run(&t, w, n);
+        total += n;
+        if (got != zl || memcmp(out.data(), z.data(), zl)) {
+            size_t k = 0; while (k < got && k < zl && out[k] == z[k]) ++k;
+            printf("MISMATCH round %d kind %d n %u: got %u bytes, zlib %lu, first difference at %zu\n", r, kind, n, got, (unsigned long)zl, k);
+            if (++bad > 5) return 1;
+        }
+    }
+    printf("%d inputs, %zu bytes, %d mismatches\n", rounds, total, bad);
+    return bad != 0;
+}

@@ -1,0 +1,526 @@
+// zdeflate.h — the zlib stream that compress() (zlib 1.2.11, default level) writes for one
+// buffer, restated so that a GPU lane can produce it: one object per lane, every table the
+// algorithm needs in a caller-supplied workspace, no allocation, no recursion, no library.
+//
+// The reference stores every object as compress(header + content) (src/commit.cpp:98-105);
+// the object store writes the SAME BYTES, so whoever deflates has to make zlib's choices, all
+// of them: its hash function and chains (hash of 3 bytes, 15 bits, most recent position first,
+// at most 128 links, a quarter of that once a match of 8 is in hand, stop at 128 bytes), lazy
+// matching (a match is emitted only if the next position does not find a longer one; none is
+// looked for after a match of 16), its rule against 3-byte matches further than 4096 back,
+// blocks of 16383 symbols, its Huffman construction (heap order, ties by depth, the length
+// limit repair), its run-length code for the code lengths, and its choice between a stored, a
+// fixed and a dynamic block.  The zlib library is a third-party dependency of the reference
+// (vcpkg.json, unpinned; 1.2.11 on this system): this file follows its published algorithm
+// (deflate.c: deflate_slow, longest_match; trees.c) and is pinned by comparing its output with
+// the library's, byte for byte, on the host (tests/test_zdeflate.py) and on the GPU.
+//
+// Scope: inputs of at most 65536 bytes (framed), for which zlib's 64 KiB window never slides;
+// longer objects stay with the host library.  Compiles as plain C++ for the host tests and as
+// device code under hipcc (ZD_FN).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define ZD_FN __host__ __device__ inline
+#else
+#define ZD_FN inline
+#endif
+
+namespace zd {
+
+constexpr int kMaxInput   = 65536;          // window_size: 2 * 32 KiB
+constexpr int kHashSize   = 32768, kHashMask = 32767, kHashShift = 5;
+constexpr int kWMask      = 32767;
+constexpr int kMinMatch   = 3, kMaxMatch = 258, kMinLookahead = kMaxMatch + kMinMatch + 1;
+constexpr int kMaxDist    = 32768 - kMinLookahead;
+constexpr int kTooFar     = 4096;
+constexpr int kLitBufSize = 16384;
+constexpr int kLCodes = 286, kDCodes = 30, kBLCodes = 19, kHeapSize = 2 * kLCodes + 1, kLiterals = 256;
+constexpr int kEndBlock = 256, kRep3_6 = 16, kRepz3_10 = 17, kRepz11_138 = 18, kMaxBits = 15, kMaxBLBits = 7;
+// level 6: good_length 8, max_lazy 16, nice_length 128, max_chain 128
+constexpr int kGood = 8, kLazy = 16, kNice = 128, kChain = 128;
+
+// Constant tables (trees.c: tr_static_init), built once on the host by make_tables().
+struct Tables {
+    uint8_t  length_code[256];              // match length - 3 -> length code
+    uint8_t  dist_code[512];                // distance - 1 -> distance code (two halves, see d_code)
+    uint16_t base_length[29], base_dist[30];
+    uint8_t  extra_lbits[29], extra_dbits[30], extra_blbits[19], bl_order[19];
+    uint16_t static_lcode[288]; uint8_t static_llen[288];
+    uint16_t static_dcode[30];                                  // every static distance code has 5 bits
+};
+
+inline unsigned bi_reverse_host(unsigned code, int len)
+{
+    unsigned res = 0;
+    do { res |= code & 1; code >>= 1; res <<= 1; } while (--len > 0);
+    return res >> 1;
+}
+
+inline void make_tables(Tables& t)
+{
+    static const uint8_t el[29] = {0,0,0,0,0,0,0,0,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,0};
+    static const uint8_t ed[30] = {0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,6,7,7,8,8,9,9,10,10,11,11,12,12,13,13};
+    static const uint8_t eb[19] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,2,3,7};
+    static const uint8_t bo[19] = {16,17,18,0,8,7,9,6,10,5,11,4,12,3,13,2,14,1,15};
+    for (int i = 0; i < 29; ++i) t.extra_lbits[i] = el[i];
+    for (int i = 0; i < 30; ++i) t.extra_dbits[i] = ed[i];
+    for (int i = 0; i < 19; ++i) { t.extra_blbits[i] = eb[i]; t.bl_order[i] = bo[i]; }
+    int length = 0, code;
+    for (code = 0; code < 28; code++) {
+        t.base_length[code] = uint16_t(length);
+        for (int n = 0; n < (1 << el[code]); n++) t.length_code[length++] = uint8_t(code);
+    }
+    t.base_length[28] = 0;                   // as trees.c leaves it: code 28 (length 258) has no extra bits
+    t.length_code[length - 1] = uint8_t(code);
+    int dist = 0;
+    for (code = 0; code < 16; code++) {
+        t.base_dist[code] = uint16_t(dist);
+        for (int n = 0; n < (1 << ed[code]); n++) t.dist_code[dist++] = uint8_t(code);
+    }
+    dist >>= 7;
+    for (; code < 30; code++) {
+        t.base_dist[code] = uint16_t(dist << 7);
+        for (int n = 0; n < (1 << (ed[code] - 7)); n++) t.dist_code[256 + dist++] = uint8_t(code);
+    }
+    uint16_t bl_count[kMaxBits + 1] = {0};
+    int n = 0;
+    while (n <= 143) { t.static_llen[n++] = 8; bl_count[8]++; }
+    while (n <= 255) { t.static_llen[n++] = 9; bl_count[9]++; }
+    while (n <= 279) { t.static_llen[n++] = 7; bl_count[7]++; }
+    while (n <= 287) { t.static_llen[n++] = 8; bl_count[8]++; }
+    uint16_t next_code[kMaxBits + 1];
+    unsigned c = 0;
+    for (int bits = 1; bits <= kMaxBits; bits++) { c = (c + bl_count[bits - 1]) << 1; next_code[bits] = uint16_t(c); }
+    for (n = 0; n < 288; n++) t.static_lcode[n] = uint16_t(bi_reverse_host(next_code[t.static_llen[n]]++, t.static_llen[n]));
+    for (n = 0; n < 30; n++) t.static_dcode[n] = uint16_t(bi_reverse_host(unsigned(n), 5));
+}
+
+// Per-object workspace.  head must be all zero on entry (the caller clears it); the other
+// arrays need no initialisation.
+struct Work {
+    uint16_t* head;                          // kHashSize entries
+    uint16_t* prev;                          // 32768 entries
+    uint16_t* d_buf;                         // kLitBufSize entries: match distances (0 = literal)
+    uint8_t*  l_buf;                         // kLitBufSize entries: literals / match lengths - 3
+    uint8_t*  out;                           // the stream; capacity out_cap
+    uint32_t  out_cap;
+};
+
+constexpr uint32_t work_bytes() { return kHashSize * 2 + 32768 * 2 + kLitBufSize * 2 + kLitBufSize; }
+// What compress() itself asks for (compressBound): enough for any input, stored blocks included.
+ZD_FN uint32_t bound(uint32_t n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 13; }
+
+// One Huffman tree under construction.  fc = frequency, later the code; dl = parent, later the
+// bit length (trees.c keeps each pair in a union, and the order of reads and writes below relies on it).
+template <int N> struct Tree { uint16_t fc[N]; uint16_t dl[N]; };
+
+struct State {
+    const Tables* t;
+    Work w;
+    uint32_t n;                              // input bytes
+    // trees
+    Tree<kHeapSize> lt;                      // literal/length tree (573 nodes: 286 leaves + internal)
+    Tree<2 * kDCodes + 1> dt;
+    Tree<2 * kBLCodes + 1> bt;
+    int l_max_code, d_max_code;
+    uint16_t bl_count[kMaxBits + 1];
+    int heap[kHeapSize]; int heap_len, heap_max;
+    uint8_t depth[kHeapSize];
+    uint32_t opt_len, static_len;
+    uint32_t last_lit;
+    // bit output
+    uint32_t pending;
+    uint16_t bi_buf; int bi_valid;
+    bool overflow;
+};
+
+template <class In> struct Deflater {
+    State s;
+    In in;                                   // in(i): byte i of the input, i < n
+
+    ZD_FN uint8_t at(uint32_t i) const { return i < s.n ? in(i) : uint8_t(0); }
+
+    // ---- bit output (trees.c: send_bits, bi_windup; deflate.c: put_byte)
+    ZD_FN void put_byte(uint32_t b) { if (s.pending < s.w.out_cap) s.w.out[s.pending++] = uint8_t(b); else s.overflow = true; }
+    ZD_FN void put_short(uint32_t v) { put_byte(v & 0xff); put_byte((v >> 8) & 0xff); }
+    ZD_FN void send_bits(uint32_t value, int length)
+    {
+        if (s.bi_valid > 16 - length) {
+            s.bi_buf = uint16_t(s.bi_buf | (value << s.bi_valid));
+            put_short(s.bi_buf);
+            s.bi_buf = uint16_t((value & 0xffffu) >> (16 - s.bi_valid));
+            s.bi_valid += length - 16;
+        } else {
+            s.bi_buf = uint16_t(s.bi_buf | (value << s.bi_valid));
+            s.bi_valid += length;
+        }
+    }
+    ZD_FN void bi_windup()
+    {
+        if (s.bi_valid > 8) put_short(s.bi_buf);
+        else if (s.bi_valid > 0) put_byte(s.bi_buf & 0xff);
+        s.bi_buf = 0; s.bi_valid = 0;
+    }
+    ZD_FN static unsigned bi_reverse(unsigned code, int len)
+    {
+        unsigned res = 0;
+        do { res |= code & 1; code >>= 1; res <<= 1; } while (--len > 0);
+        return res >> 1;
+    }
+
+    // ---- trees.c
+    ZD_FN void init_block()
+    {
+        for (int n = 0; n < kLCodes; n++) s.lt.fc[n] = 0;
+        for (int n = 0; n < kDCodes; n++) s.dt.fc[n] = 0;
+        for (int n = 0; n < kBLCodes; n++) s.bt.fc[n] = 0;
+        s.lt.fc[kEndBlock] = 1;
+        s.opt_len = s.static_len = 0;
+        s.last_lit = 0;
+    }
+
+    ZD_FN static bool smaller(const uint16_t* fc, const uint8_t* depth, int n, int m)
+    {
+        return fc[n] < fc[m] || (fc[n] == fc[m] && depth[n] <= depth[m]);
+    }
+    ZD_FN void pqdownheap(const uint16_t* fc, int k)
+    {
+        const int v = s.heap[k];
+        int j = k << 1;
+        while (j <= s.heap_len) {
+            if (j < s.heap_len && smaller(fc, s.depth, s.heap[j + 1], s.heap[j])) j++;
+            if (smaller(fc, s.depth, v, s.heap[j])) break;
+            s.heap[k] = s.heap[j]; k = j;
+            j <<= 1;
+        }
+        s.heap[k] = v;
+    }
+
+    // which: 0 literal/length, 1 distance, 2 bit-length tree
+    ZD_FN void gen_bitlen(uint16_t* fc, uint16_t* dl, int max_code, int which)
+    {
+        const uint8_t* extra = which == 0 ? s.t->extra_lbits : which == 1 ? s.t->extra_dbits : s.t->extra_blbits;
+        const int base = which == 0 ? kLiterals + 1 : 0;
+        const int max_length = which == 2 ? kMaxBLBits : kMaxBits;
+        int h, n, m, bits, xbits, overflow = 0;
+        for (bits = 0; bits <= kMaxBits; bits++) s.bl_count[bits] = 0;
+        dl[s.heap[s.heap_max]] = 0;
+        for (h = s.heap_max + 1; h < kHeapSize; h++) {
+            n = s.heap[h];
+            bits = dl[dl[n]] + 1;
+            if (bits > max_length) { bits = max_length; overflow++; }
+            dl[n] = uint16_t(bits);
+            if (n > max_code) continue;
+            s.bl_count[bits]++;
+            xbits = 0;
+            if (n >= base) xbits = extra[n - base];
+            const uint32_t f = fc[n];
+            s.opt_len += f * uint32_t(bits + xbits);
+            if (which == 0) s.static_len += f * uint32_t(s.t->static_llen[n] + xbits);
+            else if (which == 1) s.static_len += f * uint32_t(5 + xbits);
+        }
+        if (overflow == 0) return;
+        do {
+            bits = max_length - 1;
+            while (s.bl_count[bits] == 0) bits--;
+            s.bl_count[bits]--;
+            s.bl_count[bits + 1] = uint16_t(s.bl_count[bits + 1] + 2);
+            s.bl_count[max_length]--;
+            overflow -= 2;
+        } while (overflow > 0);
+        for (bits = max_length; bits != 0; bits--) {
+            n = s.bl_count[bits];
+            while (n != 0) {
+                m = s.heap[--h];
+                if (m > max_code) continue;
+                if (unsigned(dl[m]) != unsigned(bits)) {
+                    s.opt_len += (uint32_t(bits) - uint32_t(dl[m])) * uint32_t(fc[m]);
+                    dl[m] = uint16_t(bits);
+                }
+                n--;
+            }
+        }
+    }
+
+    ZD_FN void gen_codes(uint16_t* fc, const uint16_t* dl, int max_code)
+    {
+        uint16_t next_code[kMaxBits + 1];
+        unsigned code = 0;
+        for (int bits = 1; bits <= kMaxBits; bits++) {
+            code = (code + s.bl_count[bits - 1]) << 1;
+            next_code[bits] = uint16_t(code);
+        }
+        for (int n = 0; n <= max_code; n++) {
+            const int len = dl[n];
+            if (len == 0) continue;
+            fc[n] = uint16_t(bi_reverse(next_code[len]++, len));
+        }
+    }
+
+    ZD_FN int build_tree(uint16_t* fc, uint16_t* dl, int elems, int which)
+    {
+        int n, m, max_code = -1, node;
+        s.heap_len = 0; s.heap_max = kHeapSize;
+        for (n = 0; n < elems; n++) {
+            if (fc[n] != 0) { s.heap[++s.heap_len] = max_code = n; s.depth[n] = 0; }
+            else dl[n] = 0;
+        }
+        while (s.heap_len < 2) {
+            node = s.heap[++s.heap_len] = (max_code < 2 ? ++max_code : 0);
+            fc[node] = 1;
+            s.depth[node] = 0;
+            s.opt_len--;
+            if (which == 0) s.static_len -= s.t->static_llen[node];
+            else if (which == 1) s.static_len -= 5;
+        }
+        for (n = s.heap_len / 2; n >= 1; n--) pqdownheap(fc, n);
+        node = elems;
+        do {
+            n = s.heap[1];
+            s.heap[1] = s.heap[s.heap_len--];
+            pqdownheap(fc, 1);
+            m = s.heap[1];
+            s.heap[--s.heap_max] = n;
+            s.heap[--s.heap_max] = m;
+            fc[node] = uint16_t(fc[n] + fc[m]);
+            s.depth[node] = uint8_t((s.depth[n] >= s.depth[m] ? s.depth[n] : s.depth[m]) + 1);
+            dl[n] = dl[m] = uint16_t(node);
+            s.heap[1] = node++;
+            pqdownheap(fc, 1);
+        } while (s.heap_len >= 2);
+        s.heap[--s.heap_max] = s.heap[1];
+        gen_bitlen(fc, dl, max_code, which);
+        gen_codes(fc, dl, max_code);
+        return max_code;
+    }
+
+    ZD_FN void scan_tree(uint16_t* dl, int max_code)
+    {
+        int prevlen = -1, curlen, nextlen = dl[0], count = 0, max_count = 7, min_count = 4;
+        if (nextlen == 0) { max_count = 138; min_count = 3; }
+        dl[max_code + 1] = 0xffff;
+        for (int n = 0; n <= max_code; n++) {
+            curlen = nextlen; nextlen = dl[n + 1];
+            if (++count < max_count && curlen == nextlen) continue;
+            else if (count < min_count) s.bt.fc[curlen] = uint16_t(s.bt.fc[curlen] + count);
+            else if (curlen != 0) { if (curlen != prevlen) s.bt.fc[curlen]++; s.bt.fc[kRep3_6]++; }
+            else if (count <= 10) s.bt.fc[kRepz3_10]++;
+            else s.bt.fc[kRepz11_138]++;
+            count = 0; prevlen = curlen;
+            if (nextlen == 0) { max_count = 138; min_count = 3; }
+            else if (curlen == nextlen) { max_count = 6; min_count = 3; }
+            else { max_count = 7; min_count = 4; }
+        }
+    }
+
+    ZD_FN void send_bl(int c) { send_bits(s.bt.fc[c], s.bt.dl[c]); }
+    ZD_FN void send_tree(const uint16_t* dl, int max_code)
+    {
+        int prevlen = -1, curlen, nextlen = dl[0], count = 0, max_count = 7, min_count = 4;
+        if (nextlen == 0) { max_count = 138; min_count = 3; }
+        for (int n = 0; n <= max_code; n++) {
+            curlen = nextlen; nextlen = dl[n + 1];
+            if (++count < max_count && curlen == nextlen) continue;
+            else if (count < min_count) { do { send_bl(curlen); } while (--count != 0); }
+            else if (curlen != 0) {
+                if (curlen != prevlen) { send_bl(curlen); count--; }
+                send_bl(kRep3_6); send_bits(uint32_t(count - 3), 2);
+            } else if (count <= 10) { send_bl(kRepz3_10); send_bits(uint32_t(count - 3), 3); }
+            else { send_bl(kRepz11_138); send_bits(uint32_t(count - 11), 7); }
+            count = 0; prevlen = curlen;
+            if (nextlen == 0) { max_count = 138; min_count = 3; }
+            else if (curlen == nextlen) { max_count = 6; min_count = 3; }
+            else { max_count = 7; min_count = 4; }
+        }
+    }
+
+    ZD_FN int build_bl_tree()
+    {
+        scan_tree(s.lt.dl, s.l_max_code);
+        scan_tree(s.dt.dl, s.d_max_code);
+        build_tree(s.bt.fc, s.bt.dl, kBLCodes, 2);
+        int max_blindex;
+        for (max_blindex = kBLCodes - 1; max_blindex >= 3; max_blindex--)
+            if (s.bt.dl[s.t->bl_order[max_blindex]] != 0) break;
+        s.opt_len += 3 * (uint32_t(max_blindex) + 1) + 5 + 5 + 4;
+        return max_blindex;
+    }
+
+    ZD_FN unsigned d_code(unsigned dist) const { return dist < 256 ? s.t->dist_code[dist] : s.t->dist_code[256 + (dist >> 7)]; }
+
+    ZD_FN void compress_block(bool fixed)
+    {
+        uint32_t lx = 0;
+        if (s.last_lit != 0) do {
+            unsigned dist = s.w.d_buf[lx];
+            unsigned lc = s.w.l_buf[lx++];
+            if (dist == 0) {
+                if (fixed) send_bits(s.t->static_lcode[lc], s.t->static_llen[lc]); else send_bits(s.lt.fc[lc], s.lt.dl[lc]);
+            } else {
+                unsigned code = s.t->length_code[lc];
+                const unsigned sym = code + kLiterals + 1;
+                if (fixed) send_bits(s.t->static_lcode[sym], s.t->static_llen[sym]); else send_bits(s.lt.fc[sym], s.lt.dl[sym]);
+                int extra = s.t->extra_lbits[code];
+                if (extra != 0) { lc -= s.t->base_length[code]; send_bits(lc, extra); }
+                dist--;
+                code = d_code(dist);
+                if (fixed) send_bits(s.t->static_dcode[code], 5); else send_bits(s.dt.fc[code], s.dt.dl[code]);
+                extra = s.t->extra_dbits[code];
+                if (extra != 0) { dist -= s.t->base_dist[code]; send_bits(dist, extra); }
+            }
+        } while (lx < s.last_lit);
+        if (fixed) send_bits(s.t->static_lcode[kEndBlock], s.t->static_llen[kEndBlock]);
+        else send_bits(s.lt.fc[kEndBlock], s.lt.dl[kEndBlock]);
+    }
+
+    // _tr_flush_block: the block is input bytes [block_start, block_start + stored_len)
+    ZD_FN void flush_block(uint32_t block_start, uint32_t stored_len, int last)
+    {
+        s.l_max_code = build_tree(s.lt.fc, s.lt.dl, kLCodes, 0);
+        s.d_max_code = build_tree(s.dt.fc, s.dt.dl, kDCodes, 1);
+        const int max_blindex = build_bl_tree();
+        uint32_t opt_lenb = (s.opt_len + 3 + 7) >> 3;
+        const uint32_t static_lenb = (s.static_len + 3 + 7) >> 3;
+        if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+        if (stored_len + 4 <= opt_lenb) {
+            send_bits(uint32_t((0 << 1) + last), 3);
+            bi_windup();
+            put_short(stored_len & 0xffff);
+            put_short(~stored_len & 0xffff);
+            for (uint32_t i = 0; i < stored_len; ++i) put_byte(at(block_start + i));
+        } else if (static_lenb == opt_lenb) {
+            send_bits(uint32_t((1 << 1) + last), 3);
+            compress_block(true);
+        } else {
+            send_bits(uint32_t((2 << 1) + last), 3);
+            const int lcodes = s.l_max_code + 1, dcodes = s.d_max_code + 1, blcodes = max_blindex + 1;
+            send_bits(uint32_t(lcodes - 257), 5);
+            send_bits(uint32_t(dcodes - 1), 5);
+            send_bits(uint32_t(blcodes - 4), 4);
+            for (int rank = 0; rank < blcodes; rank++) send_bits(s.bt.dl[s.t->bl_order[rank]], 3);
+            send_tree(s.lt.dl, lcodes - 1);
+            send_tree(s.dt.dl, dcodes - 1);
+            compress_block(false);
+        }
+        init_block();
+        if (last) bi_windup();
+    }
+
+    // ---- deflate.c
+    ZD_FN bool tally(unsigned dist, unsigned lc)
+    {
+        s.w.d_buf[s.last_lit] = uint16_t(dist);
+        s.w.l_buf[s.last_lit++] = uint8_t(lc);
+        if (dist == 0) s.lt.fc[lc]++;
+        else {
+            dist--;
+            s.lt.fc[s.t->length_code[lc] + kLiterals + 1]++;
+            s.dt.fc[d_code(dist)]++;
+        }
+        return s.last_lit == kLitBufSize - 1;
+    }
+
+    ZD_FN uint32_t longest_match(uint32_t strstart, uint32_t lookahead, uint32_t cur_match, uint32_t prev_length,
+                                 uint32_t& match_start)
+    {
+        unsigned chain_length = kChain;
+        int best_len = int(prev_length);
+        int nice_match = kNice;
+        const uint32_t limit = strstart > uint32_t(kMaxDist) ? strstart - uint32_t(kMaxDist) : 0;
+        uint8_t scan_end1 = at(strstart + uint32_t(best_len) - 1), scan_end = at(strstart + uint32_t(best_len));
+        if (prev_length >= uint32_t(kGood)) chain_length >>= 2;
+        if (uint32_t(nice_match) > lookahead) nice_match = int(lookahead);
+        const uint8_t scan0 = at(strstart), scan1 = at(strstart + 1);
+        do {
+            if (at(cur_match + uint32_t(best_len)) != scan_end || at(cur_match + uint32_t(best_len) - 1) != scan_end1 ||
+                at(cur_match) != scan0 || at(cur_match + 1) != scan1)
+                continue;
+            // bytes 0 and 1 match; zlib's loop assumes byte 2 does too (same hash) and compares from byte 3 on, but a
+            // hash collision is settled by the length it then finds, which starts counting at 2: compare from 2 here
+            int len = 2;
+            while (len < kMaxMatch && at(strstart + uint32_t(len)) == at(cur_match + uint32_t(len))) ++len;
+            if (len > best_len) {
+                match_start = cur_match;
+                best_len = len;
+                if (len >= nice_match) break;
+                scan_end1 = at(strstart + uint32_t(best_len) - 1);
+                scan_end = at(strstart + uint32_t(best_len));
+            }
+        } while ((cur_match = s.w.prev[cur_match & kWMask]) > limit && --chain_length != 0);
+        if (uint32_t(best_len) <= lookahead) return uint32_t(best_len);
+        return lookahead;
+    }
+
+    // The whole stream for input [0, n).  Returns its length, 0 if out_cap was too small.
+    ZD_FN uint32_t run(const Tables* tables, const Work& work, uint32_t n)
+    {
+        s.t = tables; s.w = work; s.n = n;
+        s.pending = 0; s.bi_buf = 0; s.bi_valid = 0; s.overflow = false;
+        init_block();
+        put_byte(0x78); put_byte(0x9c);                                   // deflate, 32 KiB window, default level
+
+        uint32_t strstart = 0, lookahead = n, block_start = 0;
+        uint32_t match_length = kMinMatch - 1, prev_length = kMinMatch - 1, match_start = 0, prev_match = 0;
+        bool match_available = false;
+        uint32_t ins_h = 0;
+        if (n >= 2) ins_h = ((uint32_t(at(0)) << kHashShift) ^ at(1)) & kHashMask;
+
+        auto insert = [&](uint32_t str) -> uint32_t {                   // INSERT_STRING; returns the previous head
+            ins_h = ((ins_h << kHashShift) ^ at(str + 2)) & kHashMask;
+            const uint32_t head = s.w.head[ins_h];
+            s.w.prev[str & kWMask] = uint16_t(head);
+            s.w.head[ins_h] = uint16_t(str);
+            return head;
+        };
+
+        while (lookahead != 0) {
+            uint32_t hash_head = 0;
+            if (lookahead >= uint32_t(kMinMatch)) hash_head = insert(strstart);
+            prev_length = match_length; prev_match = match_start;
+            match_length = kMinMatch - 1;
+            if (hash_head != 0 && prev_length < uint32_t(kLazy) && strstart - hash_head <= uint32_t(kMaxDist)) {
+                match_length = longest_match(strstart, lookahead, hash_head, prev_length, match_start);
+                if (match_length <= 5 && match_length == uint32_t(kMinMatch) && strstart - match_start > uint32_t(kTooFar))
+                    match_length = kMinMatch - 1;
+            }
+            if (prev_length >= uint32_t(kMinMatch) && match_length <= prev_length) {
+                const uint32_t max_insert = strstart + lookahead - kMinMatch;
+                const bool bflush = tally(strstart - 1 - prev_match, prev_length - kMinMatch);
+                lookahead -= prev_length - 1;
+                prev_length -= 2;
+                do {
+                    if (++strstart <= max_insert) insert(strstart);
+                } while (--prev_length != 0);
+                match_available = false;
+                match_length = kMinMatch - 1;
+                strstart++;
+                if (bflush) { flush_block(block_start, strstart - block_start, 0); block_start = strstart; }
+            } else if (match_available) {
+                const bool bflush = tally(0, at(strstart - 1));
+                if (bflush) { flush_block(block_start, strstart - block_start, 0); block_start = strstart; }
+                strstart++;
+                lookahead--;
+            } else {
+                match_available = true;
+                strstart++;
+                lookahead--;
+            }
+        }
+        if (match_available) tally(0, at(strstart - 1));
+        flush_block(block_start, strstart - block_start, 1);
+
+        // adler32 of the input, big-endian
+        uint32_t a = 1, b = 0;
+        for (uint32_t i = 0; i < n;) {
+            const uint32_t end = i + 5552 < n ? i + 5552 : n;
+            for (; i < end; ++i) { a += in(i); b += a; }
+            a %= 65521u; b %= 65521u;
+        }
+        put_byte(b >> 8); put_byte(b & 0xff); put_byte(a >> 8); put_byte(a & 0xff);
+        return s.overflow ? 0 : s.pending;
+    }
+};
+
+}  // namespace zd
