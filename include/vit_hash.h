@@ -237,6 +237,31 @@ int vit_bin_order(const uint32_t *nblocks, uint64_t n, uint32_t *order);
 int vit_bin_order_device(vit_hasher *h, int dev, const uint32_t *d_nblocks, uint64_t n,
                          uint32_t *d_order, void *stream);
 
+/* ---- loose-object contents on the device ------------------------------------- */
+
+/* The zlib stream of every object of a device-resident arena: the bytes the
+ * reference stores, compress(header + content) at the default level
+ * (src/commit.cpp:98-105), made by one GPU lane per object with the zlib library's
+ * own choices, so that the files are identical to the reference's.  Object i's
+ * stream is written to d_out + d_out_offsets[i], where the caller has left room
+ * for vit_deflate_bound(framed length) bytes, and its length to d_out_lens[i].
+ * A length of 0 means the object was not done here and is the host's to deflate:
+ * its framed length (header + content) exceeds 65536 bytes, the range in which
+ * zlib's window never slides, or its slot was bad (status word, as for the
+ * hashing launches).  The arena is the one the hashing entry points take (message
+ * words as native dwords, padded blocks); all pointers are device pointers on
+ * queue `dev`; asynchronous on `stream` (NULL = the queue's own).  On first use the
+ * library allocates 176 KiB of device memory per object in flight (option
+ * "deflate_lanes", default 65536: 11.5 GB) and keeps it with the queue. */
+int vit_deflate_arena_device(vit_hasher *h, int dev, const void *d_arena, uint64_t arena_bytes,
+                             const uint64_t *d_offsets, const uint32_t *d_nblocks, uint64_t n,
+                             uint8_t *d_out, const uint64_t *d_out_offsets, uint32_t *d_out_lens,
+                             void *stream);
+
+/* Room a stream of that framed length may need (what compressBound() gives);
+ * 0 if the length is beyond what the device does. */
+uint32_t vit_deflate_bound(uint64_t framed_len);
+
 /* The multi-GPU partition vit_hash_objects applies: queue_of[i] = device queue
  * (0 .. n_queues-1) that hashes object i, balanced by block count (bytes), not
  * by object count; objects that are large against a fair share are placed

@@ -13,8 +13,9 @@ struct PtrIn { const uint8_t* p; uint8_t operator()(uint32_t i) const { return p
 int main(int argc, char** argv) {
     int rounds = argc > 1 ? atoi(argv[1]) : 2000;
     zd::Tables t; zd::make_tables(t);
-    std::vector<uint16_t> head(zd::kHashSize), prev(32768), dbuf(zd::kLitBufSize);
-    std::vector<uint8_t> lbuf(zd::kLitBufSize);
+    std::vector<uint16_t> head(zd::kHashSize * 3), prev(32768 * 3), dbuf(zd::kLitBufSize * 3);
+    std::vector<uint8_t> lbuf(zd::kLitBufSize * 3);
+    std::vector<uint16_t> small(zd::kSmallEntries * 5);
     std::mt19937_64 rng(atoi(argc > 2 ? argv[2] : "777"));
     static zd::Deflater<PtrIn> d;
     int bad = 0; size_t total = 0;
@@ -37,7 +38,8 @@ int main(int argc, char** argv) {
         if (compress2(z.data(), &zl, in.data(), n, 6) != Z_OK) { puts("zlib failed"); return 2; }
         std::fill(head.begin(), head.end(), 0);
         std::vector<uint8_t> out(zd::bound(n));
-        zd::Work w{head.data(), prev.data(), dbuf.data(), lbuf.data(), out.data(), uint32_t(out.size())};
+        const uint32_t st = r % 2 ? 3 : 1;                     // the arrays strided as the GPU lanes interleave theirs, and plain
+        zd::Work w{{head.data(), st}, {prev.data(), st}, {dbuf.data(), st}, {lbuf.data(), st}, small.data() + (r % 3), uint32_t(r % 2 ? 5 : 1), out.data(), uint32_t(out.size())};
         d.in = PtrIn{in.data()};
         uint32_t got = d.run(&t, w, n);
         total += n;

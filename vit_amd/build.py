@@ -21,7 +21,7 @@ CLI = os.path.join(HERE, "bin", "vit")
 DRIVER = os.path.join(HERE, "bin", "option_a_driver")
 DRIVER_SOURCE = os.path.join(ROOT, "tests", "option_a_driver.cpp")
 
-LIB_SOURCES = ["kernels.hip", "hasher.cpp", "packer.cpp", "sha1_host.cpp"]
+LIB_SOURCES = ["kernels.hip", "deflate_kernels.hip", "hasher.cpp", "packer.cpp", "sha1_host.cpp"]
 CLI_SOURCES = ["object_store.cpp", "change_detect.cpp", "vit_cli.cpp"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "-I" + os.path.join(ROOT, "include")]
 

@@ -80,6 +80,8 @@ struct Queue {
     bool      grew_this_call = false;                      // a pinned staging arena was (re)allocated during the call
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     void* sort_scratch = nullptr; size_t sort_scratch_bytes = 0;   // vit_bin_order_device
+    uint8_t* z_workspace = nullptr; uint32_t z_lanes = 0;          // vit_deflate_arena_device: tables of the objects in flight
+    void* z_tables = nullptr;                                      // ... and zlib's constant tables
     std::vector<hipEvent_t> timing;                       // pool for vit_time_hash_device
     uint64_t* wave_trace = nullptr;                       // diagnostics: device buffer, 32 bytes per wave, that the next
                                                           // launches fill with their waves' timeline (tools/wave_timeline.py)
@@ -129,6 +131,8 @@ struct vit_hasher {
     double host_bias = 1;                                 // see the end of hash_batch
     uint64_t calibrate_ns = 0;
     uint64_t fail_at_chunk = 0;                           // fault injection for tests: 0 = off
+    int deflate_occupancy = 4;                            // waves per SIMD the deflate kernel is compiled for (1, 2, 4, 8)
+    uint32_t deflate_lanes = 65536;                       // objects the deflate kernel keeps in flight (176 KiB of device memory each)
     std::atomic<uint64_t> objects_gpu{0}, objects_host{0}, bytes_host{0}, blocks_gpu{0}, bytes_h2d{0}, launches{0};
     uint64_t last_host_threshold = 0, last_host_objects = 0;
     uint64_t last_kernel_ns = 0, last_pack_ns = 0, last_total_ns = 0;
@@ -822,6 +826,8 @@ void vit_hasher_destroy(vit_hasher* h)
         if (q.ev_a) (void)hipEventDestroy(q.ev_a);
         if (q.ev_b) (void)hipEventDestroy(q.ev_b);
         if (q.sort_scratch) (void)hipFree(q.sort_scratch);
+        if (q.z_workspace) (void)hipFree(q.z_workspace);
+        if (q.z_tables) (void)hipFree(q.z_tables);
         for (hipEvent_t e : q.timing) (void)hipEventDestroy(e);
         for (hipStream_t st : q.stream) if (st) (void)hipStreamDestroy(st);
     }
@@ -859,6 +865,8 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     else if (k == "pack_rate") rate(h->pack_rate, h->pack_fixed);
     else if (k == "host_bias_percent") h->host_bias = value ? double(value) / 100.0 : 1.0;
     else if (k == "debug_fail_at_chunk") h->fail_at_chunk = value;
+    else if (k == "deflate_occupancy") h->deflate_occupancy = int(value);
+    else if (k == "deflate_lanes") h->deflate_lanes = uint32_t(std::min<uint64_t>(std::max<uint64_t>(value, 64), 1u << 20) / 64 * 64);
     else if (k == "sched_waves") h->sched_waves = uint32_t(value > 8 ? 8 : value);
     else if (k == "sched_share_below") h->sched_share_below = uint32_t(value > 0xFFFFFFFEull ? 0xFFFFFFFEu : value);
     else if (k == "sched_min_groups") h->sched_min_groups = uint32_t(value > 0xFFFFFFFFull ? 0xFFFFFFFFu : value);
@@ -1301,6 +1309,51 @@ int vit_hash_arena_device_static(vit_hasher* h, int dev, const void* d_arena, ui
                                        h->sched_tail_percent, s));
     ++h->launches; h->objects_gpu += n;
     return VIT_OK;
+}
+
+// Device memory of the deflate kernel, made on first use: the constant tables and one
+// workspace slot per lane in flight.
+static int ensure_deflate(vit_hasher* h, Queue& q)
+{
+    if (!q.z_tables) {
+        std::vector<uint8_t> host(vit::deflate_tables_bytes());
+        vit::deflate_make_tables(host.data());
+        HIP_TRY(h, hipMalloc(&q.z_tables, host.size()));
+        HIP_TRY(h, hipMemcpy(q.z_tables, host.data(), host.size(), hipMemcpyHostToDevice));
+    }
+    if (q.z_lanes != h->deflate_lanes) {
+        for (hipStream_t st : q.stream) HIP_TRY(h, hipStreamSynchronize(st));
+        if (q.z_workspace) { HIP_TRY(h, hipFree(q.z_workspace)); q.z_workspace = nullptr; q.z_lanes = 0; }
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&q.z_workspace), vit::deflate_workspace_bytes(h->deflate_lanes)));
+        q.z_lanes = h->deflate_lanes;
+    }
+    return VIT_OK;
+}
+
+int vit_deflate_arena_device(vit_hasher* h, int dev, const void* d_arena, uint64_t arena_bytes, const uint64_t* d_offsets,
+                             const uint32_t* d_nblocks, uint64_t n, uint8_t* d_out, const uint64_t* d_out_offsets,
+                             uint32_t* d_out_lens, void* stream)
+{
+    Queue* q = queue_of(h, dev);
+    if (!q) return h ? fail(h, VIT_ERR_ARG, "no device queue %d", dev) : VIT_ERR_ARG;
+    if (n == 0) return VIT_OK;
+    if (!d_arena || !d_offsets || !d_nblocks || !d_out || !d_out_offsets || !d_out_lens) return fail(h, VIT_ERR_ARG, "null argument");
+    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 - 1 objects in one call");
+    if (reinterpret_cast<uintptr_t>(d_arena) & 15) return fail(h, VIT_ERR_RANGE, "arena not 16-byte aligned");
+    HIP_TRY(h, hipSetDevice(q->device));
+    if (int rc = ensure_deflate(h, *q)) return rc;
+    vit::DeflateBatch b;
+    b.arena = static_cast<const uint8_t*>(d_arena); b.arena_bytes = arena_bytes;
+    b.offsets = d_offsets; b.nblocks = d_nblocks; b.n = uint32_t(n);
+    b.out = d_out; b.out_off = d_out_offsets; b.out_len = d_out_lens;
+    b.workspace = q->z_workspace; b.tables_raw = q->z_tables; b.status = q->d_status;
+    HIP_TRY(h, vit::launch_deflate(b, q->z_lanes, h->deflate_occupancy, stream ? static_cast<hipStream_t>(stream) : q->stream[0]));
+    return VIT_OK;
+}
+
+uint32_t vit_deflate_bound(uint64_t framed_len)
+{
+    return framed_len > vit::deflate_max_input() ? 0u : vit::deflate_bound(uint32_t(framed_len));
 }
 
 int vit_bin_order_device(vit_hasher* h, int dev, const uint32_t* d_nblocks, uint64_t n, uint32_t* d_order, void* stream)

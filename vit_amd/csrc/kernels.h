@@ -114,6 +114,27 @@ hipError_t launch_sha1_static(KernelVariant v, DeviceBatch b, void* scratch_ptr,
 // SIMDs of the current device (compute units x 4).
 hipError_t device_simds(uint32_t* out);
 
+// The zlib streams of the objects of an arena (what the reference's compress() call writes for each,
+// src/commit.cpp:98-105), one object per lane; see deflate_kernels.hip.  Object i's stream goes to
+// out + out_off[i] (room for deflate_bound(framed length) bytes) and its length to out_len[i]; 0 there
+// means the object is not the kernel's to do (framed length above deflate_max_input(), or bad input:
+// status word) and is left to the host.  workspace: deflate_workspace_bytes(lanes) bytes of device
+// memory, lanes a multiple of 64: the objects in flight at once.
+struct DeflateBatch {
+    const uint8_t*  arena; uint64_t arena_bytes;
+    const uint64_t* offsets; const uint32_t* nblocks; uint32_t n;
+    uint8_t*        out; const uint64_t* out_off; uint32_t* out_len;
+    uint8_t*        workspace;
+    const void*     tables_raw;   // device copy of what deflate_make_tables() wrote
+    uint32_t*       status;
+};
+uint64_t deflate_workspace_bytes(uint32_t lanes);
+uint64_t deflate_tables_bytes();
+void deflate_make_tables(void* host_dst);
+uint32_t deflate_bound(uint32_t framed_len);
+uint32_t deflate_max_input();
+hipError_t launch_deflate(const DeflateBatch& b, uint32_t lanes, int waves_per_simd, hipStream_t stream);
+
 // Compute-only ceiling: every lane runs `blocks_per_lane` SHA-1 compressions on
 // register-resident data (no loads in the loop).  out: one dword per lane.
 hipError_t launch_valu_peak(uint32_t* out, uint32_t n_lanes, uint32_t blocks_per_lane,

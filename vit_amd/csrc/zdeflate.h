@@ -97,37 +97,51 @@ inline void make_tables(Tables& t)
     for (n = 0; n < 30; n++) t.static_dcode[n] = uint16_t(bi_reverse_host(unsigned(n), 5));
 }
 
+// A small array of 16-bit entries whose elements lie `stride` entries apart: on the GPU the 64
+// lanes of a wave interleave theirs (stride 64, lane l starting at entry l), so that lanes
+// reading the same index of their own arrays — the common case in the tree code — touch one
+// cache line between them; on the host the stride is 1.
+struct Arr16 {
+    uint16_t* p; uint32_t stride;
+    ZD_FN uint16_t& operator[](int i) const { return p[uint32_t(i) * stride]; }
+};
+struct Arr8 {
+    uint8_t* p; uint32_t stride;
+    ZD_FN uint8_t& operator[](int i) const { return p[uint32_t(i) * stride]; }
+};
+
+// Entries of the small arrays, in this order, in Work::small.
+constexpr int kLtN = kHeapSize, kDtN = 2 * kDCodes + 1, kBtN = 2 * kBLCodes + 1;
+constexpr int kSmallEntries = 2 * kLtN + 2 * kDtN + 2 * kBtN + kHeapSize /*heap*/ + kHeapSize /*depth*/ + 16 /*bl_count*/ + 16 /*next_code*/;
+
 // Per-object workspace.  head must be all zero on entry (the caller clears it); the other
 // arrays need no initialisation.
 struct Work {
-    uint16_t* head;                          // kHashSize entries
-    uint16_t* prev;                          // 32768 entries
-    uint16_t* d_buf;                         // kLitBufSize entries: match distances (0 = literal)
-    uint8_t*  l_buf;                         // kLitBufSize entries: literals / match lengths - 3
+    Arr16 head;                              // kHashSize entries
+    Arr16 prev;                              // 32768 entries
+    Arr16 d_buf;                             // kLitBufSize entries: match distances (0 = literal)
+    Arr8  l_buf;                             // kLitBufSize entries: literals / match lengths - 3
+    uint16_t* small;                         // kSmallEntries entries, `small_stride` apart: the trees, heap, counts
+    uint32_t  small_stride;
     uint8_t*  out;                           // the stream; capacity out_cap
     uint32_t  out_cap;
 };
 
 constexpr uint32_t work_bytes() { return kHashSize * 2 + 32768 * 2 + kLitBufSize * 2 + kLitBufSize; }
+constexpr uint32_t small_bytes() { return kSmallEntries * 2; }
 // What compress() itself asks for (compressBound): enough for any input, stored blocks included.
 ZD_FN uint32_t bound(uint32_t n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 13; }
 
-// One Huffman tree under construction.  fc = frequency, later the code; dl = parent, later the
-// bit length (trees.c keeps each pair in a union, and the order of reads and writes below relies on it).
-template <int N> struct Tree { uint16_t fc[N]; uint16_t dl[N]; };
-
+// fc = frequency, later the code; dl = parent, later the bit length (trees.c keeps each pair in a
+// union, and the order of reads and writes below relies on it).
 struct State {
     const Tables* t;
     Work w;
     uint32_t n;                              // input bytes
-    // trees
-    Tree<kHeapSize> lt;                      // literal/length tree (573 nodes: 286 leaves + internal)
-    Tree<2 * kDCodes + 1> dt;
-    Tree<2 * kBLCodes + 1> bt;
+    Arr16 lt_fc, lt_dl, dt_fc, dt_dl, bt_fc, bt_dl;   // literal/length tree (573 nodes: 286 leaves + internal), distance, bit-length
+    Arr16 heap, depth, bl_count, next_code;
     int l_max_code, d_max_code;
-    uint16_t bl_count[kMaxBits + 1];
-    int heap[kHeapSize]; int heap_len, heap_max;
-    uint8_t depth[kHeapSize];
+    int heap_len, heap_max;
     uint32_t opt_len, static_len;
     uint32_t last_lit;
     // bit output
@@ -173,33 +187,33 @@ template <class In> struct Deflater {
     // ---- trees.c
     ZD_FN void init_block()
     {
-        for (int n = 0; n < kLCodes; n++) s.lt.fc[n] = 0;
-        for (int n = 0; n < kDCodes; n++) s.dt.fc[n] = 0;
-        for (int n = 0; n < kBLCodes; n++) s.bt.fc[n] = 0;
-        s.lt.fc[kEndBlock] = 1;
+        for (int n = 0; n < kLCodes; n++) s.lt_fc[n] = 0;
+        for (int n = 0; n < kDCodes; n++) s.dt_fc[n] = 0;
+        for (int n = 0; n < kBLCodes; n++) s.bt_fc[n] = 0;
+        s.lt_fc[kEndBlock] = 1;
         s.opt_len = s.static_len = 0;
         s.last_lit = 0;
     }
 
-    ZD_FN static bool smaller(const uint16_t* fc, const uint8_t* depth, int n, int m)
+    ZD_FN static bool smaller(const Arr16& fc, const Arr16& depth, int n, int m)
     {
         return fc[n] < fc[m] || (fc[n] == fc[m] && depth[n] <= depth[m]);
     }
-    ZD_FN void pqdownheap(const uint16_t* fc, int k)
+    ZD_FN void pqdownheap(const Arr16& fc, int k)
     {
         const int v = s.heap[k];
         int j = k << 1;
         while (j <= s.heap_len) {
             if (j < s.heap_len && smaller(fc, s.depth, s.heap[j + 1], s.heap[j])) j++;
             if (smaller(fc, s.depth, v, s.heap[j])) break;
-            s.heap[k] = s.heap[j]; k = j;
+            { const uint16_t hj = s.heap[j]; s.heap[k] = hj; } k = j;
             j <<= 1;
         }
-        s.heap[k] = v;
+        s.heap[k] = uint16_t(v);
     }
 
     // which: 0 literal/length, 1 distance, 2 bit-length tree
-    ZD_FN void gen_bitlen(uint16_t* fc, uint16_t* dl, int max_code, int which)
+    ZD_FN void gen_bitlen(const Arr16& fc, const Arr16& dl, int max_code, int which)
     {
         const uint8_t* extra = which == 0 ? s.t->extra_lbits : which == 1 ? s.t->extra_dbits : s.t->extra_blbits;
         const int base = which == 0 ? kLiterals + 1 : 0;
@@ -244,9 +258,9 @@ template <class In> struct Deflater {
         }
     }
 
-    ZD_FN void gen_codes(uint16_t* fc, const uint16_t* dl, int max_code)
+    ZD_FN void gen_codes(const Arr16& fc, const Arr16& dl, int max_code)
     {
-        uint16_t next_code[kMaxBits + 1];
+        const Arr16& next_code = s.next_code;
         unsigned code = 0;
         for (int bits = 1; bits <= kMaxBits; bits++) {
             code = (code + s.bl_count[bits - 1]) << 1;
@@ -255,20 +269,21 @@ template <class In> struct Deflater {
         for (int n = 0; n <= max_code; n++) {
             const int len = dl[n];
             if (len == 0) continue;
-            fc[n] = uint16_t(bi_reverse(next_code[len]++, len));
+            { const unsigned c = next_code[len]; next_code[len] = uint16_t(c + 1); fc[n] = uint16_t(bi_reverse(c, len)); }
         }
     }
 
-    ZD_FN int build_tree(uint16_t* fc, uint16_t* dl, int elems, int which)
+    ZD_FN int build_tree(const Arr16& fc, const Arr16& dl, int elems, int which)
     {
         int n, m, max_code = -1, node;
         s.heap_len = 0; s.heap_max = kHeapSize;
         for (n = 0; n < elems; n++) {
-            if (fc[n] != 0) { s.heap[++s.heap_len] = max_code = n; s.depth[n] = 0; }
+            if (fc[n] != 0) { max_code = n; s.heap[++s.heap_len] = uint16_t(n); s.depth[n] = 0; }
             else dl[n] = 0;
         }
         while (s.heap_len < 2) {
-            node = s.heap[++s.heap_len] = (max_code < 2 ? ++max_code : 0);
+            node = (max_code < 2 ? ++max_code : 0);
+            s.heap[++s.heap_len] = uint16_t(node);
             fc[node] = 1;
             s.depth[node] = 0;
             s.opt_len--;
@@ -279,24 +294,24 @@ template <class In> struct Deflater {
         node = elems;
         do {
             n = s.heap[1];
-            s.heap[1] = s.heap[s.heap_len--];
+            s.heap[1] = s.heap[s.heap_len]; s.heap_len--;
             pqdownheap(fc, 1);
             m = s.heap[1];
-            s.heap[--s.heap_max] = n;
-            s.heap[--s.heap_max] = m;
+            s.heap[--s.heap_max] = uint16_t(n);
+            s.heap[--s.heap_max] = uint16_t(m);
             fc[node] = uint16_t(fc[n] + fc[m]);
-            s.depth[node] = uint8_t((s.depth[n] >= s.depth[m] ? s.depth[n] : s.depth[m]) + 1);
+            s.depth[node] = uint16_t((s.depth[n] >= s.depth[m] ? s.depth[n] : s.depth[m]) + 1);
             dl[n] = dl[m] = uint16_t(node);
-            s.heap[1] = node++;
+            s.heap[1] = uint16_t(node); node++;
             pqdownheap(fc, 1);
         } while (s.heap_len >= 2);
-        s.heap[--s.heap_max] = s.heap[1];
+        { const uint16_t top = s.heap[1]; s.heap[--s.heap_max] = top; }
         gen_bitlen(fc, dl, max_code, which);
         gen_codes(fc, dl, max_code);
         return max_code;
     }
 
-    ZD_FN void scan_tree(uint16_t* dl, int max_code)
+    ZD_FN void scan_tree(const Arr16& dl, int max_code)
     {
         int prevlen = -1, curlen, nextlen = dl[0], count = 0, max_count = 7, min_count = 4;
         if (nextlen == 0) { max_count = 138; min_count = 3; }
@@ -304,10 +319,10 @@ template <class In> struct Deflater {
         for (int n = 0; n <= max_code; n++) {
             curlen = nextlen; nextlen = dl[n + 1];
             if (++count < max_count && curlen == nextlen) continue;
-            else if (count < min_count) s.bt.fc[curlen] = uint16_t(s.bt.fc[curlen] + count);
-            else if (curlen != 0) { if (curlen != prevlen) s.bt.fc[curlen]++; s.bt.fc[kRep3_6]++; }
-            else if (count <= 10) s.bt.fc[kRepz3_10]++;
-            else s.bt.fc[kRepz11_138]++;
+            else if (count < min_count) s.bt_fc[curlen] = uint16_t(s.bt_fc[curlen] + count);
+            else if (curlen != 0) { if (curlen != prevlen) s.bt_fc[curlen]++; s.bt_fc[kRep3_6]++; }
+            else if (count <= 10) s.bt_fc[kRepz3_10]++;
+            else s.bt_fc[kRepz11_138]++;
             count = 0; prevlen = curlen;
             if (nextlen == 0) { max_count = 138; min_count = 3; }
             else if (curlen == nextlen) { max_count = 6; min_count = 3; }
@@ -315,8 +330,8 @@ template <class In> struct Deflater {
         }
     }
 
-    ZD_FN void send_bl(int c) { send_bits(s.bt.fc[c], s.bt.dl[c]); }
-    ZD_FN void send_tree(const uint16_t* dl, int max_code)
+    ZD_FN void send_bl(int c) { send_bits(s.bt_fc[c], s.bt_dl[c]); }
+    ZD_FN void send_tree(const Arr16& dl, int max_code)
     {
         int prevlen = -1, curlen, nextlen = dl[0], count = 0, max_count = 7, min_count = 4;
         if (nextlen == 0) { max_count = 138; min_count = 3; }
@@ -338,12 +353,12 @@ template <class In> struct Deflater {
 
     ZD_FN int build_bl_tree()
     {
-        scan_tree(s.lt.dl, s.l_max_code);
-        scan_tree(s.dt.dl, s.d_max_code);
-        build_tree(s.bt.fc, s.bt.dl, kBLCodes, 2);
+        scan_tree(s.lt_dl, s.l_max_code);
+        scan_tree(s.dt_dl, s.d_max_code);
+        build_tree(s.bt_fc, s.bt_dl, kBLCodes, 2);
         int max_blindex;
         for (max_blindex = kBLCodes - 1; max_blindex >= 3; max_blindex--)
-            if (s.bt.dl[s.t->bl_order[max_blindex]] != 0) break;
+            if (s.bt_dl[s.t->bl_order[max_blindex]] != 0) break;
         s.opt_len += 3 * (uint32_t(max_blindex) + 1) + 5 + 5 + 4;
         return max_blindex;
     }
@@ -354,32 +369,33 @@ template <class In> struct Deflater {
     {
         uint32_t lx = 0;
         if (s.last_lit != 0) do {
-            unsigned dist = s.w.d_buf[lx];
-            unsigned lc = s.w.l_buf[lx++];
+            unsigned dist = s.w.d_buf[int(lx)];
+            unsigned lc = s.w.l_buf[int(lx)];
+            lx++;
             if (dist == 0) {
-                if (fixed) send_bits(s.t->static_lcode[lc], s.t->static_llen[lc]); else send_bits(s.lt.fc[lc], s.lt.dl[lc]);
+                if (fixed) send_bits(s.t->static_lcode[lc], s.t->static_llen[lc]); else send_bits(s.lt_fc[lc], s.lt_dl[lc]);
             } else {
                 unsigned code = s.t->length_code[lc];
                 const unsigned sym = code + kLiterals + 1;
-                if (fixed) send_bits(s.t->static_lcode[sym], s.t->static_llen[sym]); else send_bits(s.lt.fc[sym], s.lt.dl[sym]);
+                if (fixed) send_bits(s.t->static_lcode[sym], s.t->static_llen[sym]); else send_bits(s.lt_fc[sym], s.lt_dl[sym]);
                 int extra = s.t->extra_lbits[code];
                 if (extra != 0) { lc -= s.t->base_length[code]; send_bits(lc, extra); }
                 dist--;
                 code = d_code(dist);
-                if (fixed) send_bits(s.t->static_dcode[code], 5); else send_bits(s.dt.fc[code], s.dt.dl[code]);
+                if (fixed) send_bits(s.t->static_dcode[code], 5); else send_bits(s.dt_fc[code], s.dt_dl[code]);
                 extra = s.t->extra_dbits[code];
                 if (extra != 0) { dist -= s.t->base_dist[code]; send_bits(dist, extra); }
             }
         } while (lx < s.last_lit);
         if (fixed) send_bits(s.t->static_lcode[kEndBlock], s.t->static_llen[kEndBlock]);
-        else send_bits(s.lt.fc[kEndBlock], s.lt.dl[kEndBlock]);
+        else send_bits(s.lt_fc[kEndBlock], s.lt_dl[kEndBlock]);
     }
 
     // _tr_flush_block: the block is input bytes [block_start, block_start + stored_len)
     ZD_FN void flush_block(uint32_t block_start, uint32_t stored_len, int last)
     {
-        s.l_max_code = build_tree(s.lt.fc, s.lt.dl, kLCodes, 0);
-        s.d_max_code = build_tree(s.dt.fc, s.dt.dl, kDCodes, 1);
+        s.l_max_code = build_tree(s.lt_fc, s.lt_dl, kLCodes, 0);
+        s.d_max_code = build_tree(s.dt_fc, s.dt_dl, kDCodes, 1);
         const int max_blindex = build_bl_tree();
         uint32_t opt_lenb = (s.opt_len + 3 + 7) >> 3;
         const uint32_t static_lenb = (s.static_len + 3 + 7) >> 3;
@@ -399,80 +415,104 @@ template <class In> struct Deflater {
             send_bits(uint32_t(lcodes - 257), 5);
             send_bits(uint32_t(dcodes - 1), 5);
             send_bits(uint32_t(blcodes - 4), 4);
-            for (int rank = 0; rank < blcodes; rank++) send_bits(s.bt.dl[s.t->bl_order[rank]], 3);
-            send_tree(s.lt.dl, lcodes - 1);
-            send_tree(s.dt.dl, dcodes - 1);
+            for (int rank = 0; rank < blcodes; rank++) send_bits(s.bt_dl[s.t->bl_order[rank]], 3);
+            send_tree(s.lt_dl, lcodes - 1);
+            send_tree(s.dt_dl, dcodes - 1);
             compress_block(false);
         }
         init_block();
         if (last) bi_windup();
     }
 
-    // ---- deflate.c
-    ZD_FN bool tally(unsigned dist, unsigned lc)
-    {
-        s.w.d_buf[s.last_lit] = uint16_t(dist);
-        s.w.l_buf[s.last_lit++] = uint8_t(lc);
-        if (dist == 0) s.lt.fc[lc]++;
-        else {
-            dist--;
-            s.lt.fc[s.t->length_code[lc] + kLiterals + 1]++;
-            s.dt.fc[d_code(dist)]++;
-        }
-        return s.last_lit == kLitBufSize - 1;
-    }
-
-    ZD_FN uint32_t longest_match(uint32_t strstart, uint32_t lookahead, uint32_t cur_match, uint32_t prev_length,
-                                 uint32_t& match_start)
-    {
-        unsigned chain_length = kChain;
-        int best_len = int(prev_length);
-        int nice_match = kNice;
-        const uint32_t limit = strstart > uint32_t(kMaxDist) ? strstart - uint32_t(kMaxDist) : 0;
-        uint8_t scan_end1 = at(strstart + uint32_t(best_len) - 1), scan_end = at(strstart + uint32_t(best_len));
-        if (prev_length >= uint32_t(kGood)) chain_length >>= 2;
-        if (uint32_t(nice_match) > lookahead) nice_match = int(lookahead);
-        const uint8_t scan0 = at(strstart), scan1 = at(strstart + 1);
-        do {
-            if (at(cur_match + uint32_t(best_len)) != scan_end || at(cur_match + uint32_t(best_len) - 1) != scan_end1 ||
-                at(cur_match) != scan0 || at(cur_match + 1) != scan1)
-                continue;
-            // bytes 0 and 1 match; zlib's loop assumes byte 2 does too (same hash) and compares from byte 3 on, but a
-            // hash collision is settled by the length it then finds, which starts counting at 2: compare from 2 here
-            int len = 2;
-            while (len < kMaxMatch && at(strstart + uint32_t(len)) == at(cur_match + uint32_t(len))) ++len;
-            if (len > best_len) {
-                match_start = cur_match;
-                best_len = len;
-                if (len >= nice_match) break;
-                scan_end1 = at(strstart + uint32_t(best_len) - 1);
-                scan_end = at(strstart + uint32_t(best_len));
-            }
-        } while ((cur_match = s.w.prev[cur_match & kWMask]) > limit && --chain_length != 0);
-        if (uint32_t(best_len) <= lookahead) return uint32_t(best_len);
-        return lookahead;
-    }
-
+    // ---- deflate.c: deflate_slow with longest_match, INSERT_STRING and _tr_tally in line.
+    // Everything the scan touches per input byte is a local here (registers on the GPU): only
+    // the tables it must index live in memory.  The State is brought up to date around the
+    // block flushes, which happen once in 16383 symbols.
     // The whole stream for input [0, n).  Returns its length, 0 if out_cap was too small.
     ZD_FN uint32_t run(const Tables* tables, const Work& work, uint32_t n)
     {
         s.t = tables; s.w = work; s.n = n;
         s.pending = 0; s.bi_buf = 0; s.bi_valid = 0; s.overflow = false;
+        {
+            uint16_t* p = work.small;
+            const uint32_t st = work.small_stride;
+            auto take = [&](int entries) { Arr16 a{p, st}; p += uint32_t(entries) * st; return a; };
+            s.lt_fc = take(kLtN); s.lt_dl = take(kLtN);
+            s.dt_fc = take(kDtN); s.dt_dl = take(kDtN);
+            s.bt_fc = take(kBtN); s.bt_dl = take(kBtN);
+            s.heap = take(kHeapSize); s.depth = take(kHeapSize);
+            s.bl_count = take(16); s.next_code = take(16);
+        }
         init_block();
         put_byte(0x78); put_byte(0x9c);                                   // deflate, 32 KiB window, default level
 
-        uint32_t strstart = 0, lookahead = n, block_start = 0;
+        const In input = in;
+        const Arr16 head = work.head, prev = work.prev, d_buf = work.d_buf;
+        const Arr8 l_buf = work.l_buf;
+        const Arr16 lt_fc = s.lt_fc, dt_fc = s.dt_fc;
+        const uint8_t* const length_code = tables->length_code;
+        const uint8_t* const dist_code = tables->dist_code;
+        auto byte_at = [&](uint32_t i) -> uint32_t { return i < n ? uint32_t(input(i)) : 0u; };
+
+        uint32_t strstart = 0, lookahead = n, block_start = 0, last_lit = 0;
         uint32_t match_length = kMinMatch - 1, prev_length = kMinMatch - 1, match_start = 0, prev_match = 0;
         bool match_available = false;
         uint32_t ins_h = 0;
-        if (n >= 2) ins_h = ((uint32_t(at(0)) << kHashShift) ^ at(1)) & kHashMask;
+        if (n >= 2) ins_h = ((byte_at(0) << kHashShift) ^ byte_at(1)) & kHashMask;
 
         auto insert = [&](uint32_t str) -> uint32_t {                   // INSERT_STRING; returns the previous head
-            ins_h = ((ins_h << kHashShift) ^ at(str + 2)) & kHashMask;
-            const uint32_t head = s.w.head[ins_h];
-            s.w.prev[str & kWMask] = uint16_t(head);
-            s.w.head[ins_h] = uint16_t(str);
-            return head;
+            ins_h = ((ins_h << kHashShift) ^ byte_at(str + 2)) & kHashMask;
+            const uint32_t h = head[int(ins_h)];
+            prev[int(str & kWMask)] = uint16_t(h);
+            head[int(ins_h)] = uint16_t(str);
+            return h;
+        };
+        auto tally = [&](uint32_t dist, uint32_t lc) -> bool {          // _tr_tally
+            d_buf[int(last_lit)] = uint16_t(dist);
+            l_buf[int(last_lit)] = uint8_t(lc);
+            last_lit++;
+            if (dist == 0) lt_fc[int(lc)]++;
+            else {
+                dist--;
+                lt_fc[int(length_code[lc]) + kLiterals + 1]++;
+                dt_fc[int(dist < 256 ? dist_code[dist] : dist_code[256 + (dist >> 7)])]++;
+            }
+            return last_lit == uint32_t(kLitBufSize - 1);
+        };
+        auto flush = [&](int last) {
+            s.last_lit = last_lit;
+            flush_block(block_start, strstart - block_start, last);
+            last_lit = 0;
+            block_start = strstart;
+        };
+        // longest_match: the longest earlier occurrence of the bytes at strstart among the chain from cur_match
+        auto longest_match = [&](uint32_t cur_match) -> uint32_t {
+            unsigned chain_length = kChain;
+            int best_len = int(prev_length);
+            int nice_match = kNice;
+            const uint32_t limit = strstart > uint32_t(kMaxDist) ? strstart - uint32_t(kMaxDist) : 0;
+            uint32_t scan_end1 = byte_at(strstart + uint32_t(best_len) - 1), scan_end = byte_at(strstart + uint32_t(best_len));
+            if (prev_length >= uint32_t(kGood)) chain_length >>= 2;
+            if (uint32_t(nice_match) > lookahead) nice_match = int(lookahead);
+            const uint32_t scan0 = byte_at(strstart), scan1 = byte_at(strstart + 1);
+            do {
+                if (byte_at(cur_match + uint32_t(best_len)) != scan_end || byte_at(cur_match + uint32_t(best_len) - 1) != scan_end1 ||
+                    byte_at(cur_match) != scan0 || byte_at(cur_match + 1) != scan1)
+                    continue;
+                // bytes 0 and 1 match, and byte 2 with them (same hash of three bytes, wide enough to tell);
+                // zlib resumes at byte 3, which comes to the same length
+                int len = 2;
+                while (len < kMaxMatch && byte_at(strstart + uint32_t(len)) == byte_at(cur_match + uint32_t(len))) ++len;
+                if (len > best_len) {
+                    match_start = cur_match;
+                    best_len = len;
+                    if (len >= nice_match) break;
+                    scan_end1 = byte_at(strstart + uint32_t(best_len) - 1);
+                    scan_end = byte_at(strstart + uint32_t(best_len));
+                }
+            } while ((cur_match = prev[int(cur_match & kWMask)]) > limit && --chain_length != 0);
+            if (uint32_t(best_len) <= lookahead) return uint32_t(best_len);
+            return lookahead;
         };
 
         while (lookahead != 0) {
@@ -481,7 +521,7 @@ template <class In> struct Deflater {
             prev_length = match_length; prev_match = match_start;
             match_length = kMinMatch - 1;
             if (hash_head != 0 && prev_length < uint32_t(kLazy) && strstart - hash_head <= uint32_t(kMaxDist)) {
-                match_length = longest_match(strstart, lookahead, hash_head, prev_length, match_start);
+                match_length = longest_match(hash_head);
                 if (match_length <= 5 && match_length == uint32_t(kMinMatch) && strstart - match_start > uint32_t(kTooFar))
                     match_length = kMinMatch - 1;
             }
@@ -496,10 +536,10 @@ template <class In> struct Deflater {
                 match_available = false;
                 match_length = kMinMatch - 1;
                 strstart++;
-                if (bflush) { flush_block(block_start, strstart - block_start, 0); block_start = strstart; }
+                if (bflush) flush(0);
             } else if (match_available) {
-                const bool bflush = tally(0, at(strstart - 1));
-                if (bflush) { flush_block(block_start, strstart - block_start, 0); block_start = strstart; }
+                const bool bflush = tally(0, byte_at(strstart - 1));
+                if (bflush) flush(0);
                 strstart++;
                 lookahead--;
             } else {
@@ -508,14 +548,14 @@ template <class In> struct Deflater {
                 lookahead--;
             }
         }
-        if (match_available) tally(0, at(strstart - 1));
-        flush_block(block_start, strstart - block_start, 1);
+        if (match_available) tally(0, byte_at(strstart - 1));
+        flush(1);
 
         // adler32 of the input, big-endian
         uint32_t a = 1, b = 0;
         for (uint32_t i = 0; i < n;) {
             const uint32_t end = i + 5552 < n ? i + 5552 : n;
-            for (; i < end; ++i) { a += in(i); b += a; }
+            for (; i < end; ++i) { a += input(i); b += a; }
             a %= 65521u; b %= 65521u;
         }
         put_byte(b >> 8); put_byte(b & 0xff); put_byte(a >> 8); put_byte(a & 0xff);

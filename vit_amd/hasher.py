@@ -268,6 +268,29 @@ class Hasher:
         self.sync(batch["dev"])
         return batch["digests"].download(np.uint8, 20 * batch["n"]).reshape(-1, 20)
 
+    def deflate_device(self, batch, framed_lens):
+        """zlib streams of a batch from synth_arena() (vit_deflate_arena_device).  framed_lens: header + content
+        length per object (sizes the output).  Returns (list of bytes, seconds on the device)."""
+        import time
+        n = batch["n"]
+        lib = self.lib
+        cap = np.array([max(lib.vit_deflate_bound(int(L)), 16) for L in framed_lens], dtype=np.uint64)
+        cap = (cap + np.uint64(15)) // np.uint64(16) * np.uint64(16)
+        off = np.concatenate([[0], np.cumsum(cap)]).astype(np.uint64)
+        d_out = self.alloc(int(off[-1]) + 16, batch["dev"])
+        d_off = self.alloc(8 * n, batch["dev"]).upload(off[:n].copy())
+        d_len = self.alloc(4 * n, batch["dev"])
+        self.sync(batch["dev"])
+        t0 = time.perf_counter()
+        self._check(lib.vit_deflate_arena_device(self.handle, batch["dev"], batch["arena"].ptr, batch["arena_bytes"],
+                                                 batch["offsets"].ptr, batch["nblocks"].ptr, n, d_out.ptr, d_off.ptr,
+                                                 d_len.ptr, None))
+        self.sync(batch["dev"])
+        dt = time.perf_counter() - t0
+        lens = d_len.download(np.uint32, 4 * n)
+        raw = d_out.download(np.uint8, int(off[-1]))
+        return [raw[int(off[i]):int(off[i]) + int(lens[i])].tobytes() for i in range(n)], dt
+
     def time_hash_device(self, batch, order=None, warmup=1, iters=5):
         ms = (C.c_float * max(iters, 1))()
         self._check(self.lib.vit_time_hash_device(
