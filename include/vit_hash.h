@@ -250,13 +250,29 @@ int vit_bin_order_device(vit_hasher *h, int dev, const uint32_t *d_nblocks, uint
  * zlib's window never slides, or its slot was bad (status word, as for the
  * hashing launches).  The arena is the one the hashing entry points take (message
  * words as native dwords, padded blocks); all pointers are device pointers on
- * queue `dev`; asynchronous on `stream` (NULL = the queue's own).  On first use the
+ * queue `dev`; asynchronous on `stream` (NULL = the queue's own).  d_order (optional,
+ * as for vit_hash_arena_device: object indices by length, vit_bin_order) lets the 64
+ * lanes of a wave take objects of similar length, which end together.  On first use the
  * library allocates 176 KiB of device memory per object in flight (option
  * "deflate_lanes", default 65536: 11.5 GB) and keeps it with the queue. */
 int vit_deflate_arena_device(vit_hasher *h, int dev, const void *d_arena, uint64_t arena_bytes,
-                             const uint64_t *d_offsets, const uint32_t *d_nblocks, uint64_t n,
+                             const uint64_t *d_offsets, const uint32_t *d_nblocks,
+                             const uint32_t *d_order, uint64_t n,
                              uint8_t *d_out, const uint64_t *d_out_offsets, uint32_t *d_out_lens,
                              void *stream);
+
+/* The same for objects in host memory (pack, copy, kernel, copy back, chunk by
+ * chunk, on the hasher's first device queue).  Objects whose framed length exceeds
+ * option "deflate_max_bytes" (default 16384, at most 65536) are not done here: one
+ * lane gets through about 0.1 MB of input per second, so the device is for the many
+ * small objects of a batch and host cores for its long ones.  out: host memory of at
+ * least vit_deflate_out_bytes() bytes, best pinned (vit_arena_alloc).  On return
+ * stream i is out[out_off[i] .. out_off[i] + out_len[i]); out_len[i] = 0 means the
+ * object is the caller's to deflate. */
+int vit_deflate_objects(vit_hasher *h, const char *type, const uint8_t *const *data,
+                        const uint64_t *len, uint64_t n, uint8_t *out, uint64_t out_cap,
+                        uint64_t *out_off, uint32_t *out_len);
+uint64_t vit_deflate_out_bytes(const vit_hasher *h, const char *type, const uint64_t *len, uint64_t n);
 
 /* Room a stream of that framed length may need (what compressBound() gives);
  * 0 if the length is beyond what the device does. */

@@ -1,0 +1,74 @@
+"""The deflate kernel through the C ABI against the zlib library (zlib.compress at the default level, the
+reference's compress() call at src/commit.cpp:100): every stream byte for byte."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _framed(type_, data):
+    return type_.encode() + b" %d\0" % len(data) + data
+
+
+def test_device_streams_equal_zlibs_for_every_kind_of_content(hasher):
+    """vit_deflate_objects: random, text-like, constant and repetitive contents, empty objects, lengths around the
+    block and table edges; objects above deflate_max_bytes come back with length 0 (the caller's to do)."""
+    rng = np.random.default_rng(31)
+    words = [b"the ", b"quick ", b"brown ", b"fox ", b"int ", b"return ", b"void ", b"#include ", b"\n", b"    ",
+             b"for (", b"i++) {", b"}", b"const ", b"0x", b"==", b"abcabcabc"]
+    blobs = []
+    for L in [0, 1, 2, 3, 55, 56, 57, 63, 64, 65, 255, 256, 257, 4095, 4096, 4097, 16000, 16383 - 10, 16384, 20000, 40000, 65000,
+              65536 - 11, 65536 - 10, 65536, 70000] + rng.integers(0, 9000, 400).tolist():
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            d = rng.integers(0, 256, L, dtype=np.uint8).tobytes()
+        elif kind == 1:
+            d = b"".join(words[int(k)] for k in rng.integers(0, len(words), L // 3 + 1))[:L]
+        elif kind == 2:
+            d = bytes([int(rng.integers(0, 256))]) * L
+        elif kind == 3:
+            d = (rng.integers(0, 4, L, dtype=np.uint8) + 97).tobytes()
+        else:
+            base = rng.integers(0, 256, 700, dtype=np.uint8).tobytes()
+            d = (base * (L // 700 + 1))[:L]
+        blobs.append(d)
+    hasher.set_option("deflate_max_bytes", 65536)
+    try:
+        for type_ in ("blob", "tree"):
+            got, _ = hasher.deflate_objects(type_, blobs)
+            for d, z in zip(blobs, got):
+                framed = _framed(type_, d)
+                if len(framed) > 65536:
+                    assert z == b"", len(d)
+                else:
+                    assert z == zlib.compress(framed, 6), (type_, len(d))
+        hasher.set_option("deflate_max_bytes", 4096)          # the cut between the device's objects and the caller's
+        got, _ = hasher.deflate_objects("blob", blobs)
+        for d, z in zip(blobs, got):
+            framed = _framed("blob", d)
+            assert z == (zlib.compress(framed, 6) if len(framed) <= 4096 else b""), len(d)
+    finally:
+        hasher.set_option("deflate_max_bytes", 16384)
+    assert hasher.device_status() == 0
+
+
+def test_device_resident_arena_streams_and_the_files_they_make(hasher):
+    """vit_deflate_arena_device on 100,000 synthetic 4 KiB blobs resident in HBM, in order of length and without:
+    sampled streams equal zlib's and inflate to header + content."""
+    import vit_amd
+    n = 100_000
+    lens = np.random.default_rng(5).integers(0, 8200, n).astype(np.uint64)
+    b = hasher.synth_arena("blob", 0x5EED00AB, 0, n, 0, lens=lens)
+    framed = [int(l) + vit_amd.header_len("blob", int(l)) for l in lens]
+    nb = b["nblocks"].download(np.uint32, 4 * n)
+    order = hasher.alloc(4 * n).upload(vit_amd.bin_order(nb)[0])
+    plain, _ = hasher.deflate_device(b, framed)
+    binned, _ = hasher.deflate_device(b, framed, order)
+    assert plain == binned
+    for i in np.random.default_rng(6).integers(0, n, 1500).tolist() + [0, n - 1, int(np.argmax(lens)), int(np.argmin(lens))]:
+        data = vit_amd.synth_bytes(0x5EED00AB, i, int(lens[i]))
+        assert plain[i] == zlib.compress(_framed("blob", data), 6), i
+        assert zlib.decompress(plain[i]) == _framed("blob", data)
+    assert hasher.device_status() == 0

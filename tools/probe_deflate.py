@@ -21,8 +21,12 @@ rng = np.random.default_rng(8)
 lens = np.full(n, L, dtype=np.uint64) if L else np.minimum(np.exp(rng.normal(np.log(3000.0), 1.3, n)), 60000).astype(np.uint64)
 b = h.synth_arena("blob", 0x5EED00AA, 0, n, 0, lens=lens)
 framed = [int(l) + vit_amd.header_len("blob", int(l)) for l in lens]
-out, dt = h.deflate_device(b, framed)          # first call allocates the workspace
-out, dt = h.deflate_device(b, framed)
+order = None
+if not L:                                      # mixed sizes: objects by length, so a wave's 64 end together
+    nbk = b["nblocks"].download(np.uint32, 4 * n)
+    order = h.alloc(4 * n).upload(vit_amd.bin_order(nbk)[0])
+out, dt = h.deflate_device(b, framed, order)   # first call allocates the workspace
+out, dt = h.deflate_device(b, framed, order)
 bad = 0
 for i in rng.choice(n, size=check, replace=False) if check < n else range(n):
     data = vit_amd.synth_bytes(0x5EED00AA, int(i), int(lens[i]))

@@ -41,8 +41,10 @@ SIGNATURES = {
                                          C.c_uint32]),
     "vit_bin_order": (C.c_int, [vp, C.c_uint64, vp]),
     "vit_bin_order_device": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp]),
-    "vit_deflate_arena_device": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp, C.c_uint64, vp, vp, vp, vp]),
+    "vit_deflate_arena_device": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp, vp, vp]),
     "vit_deflate_bound": (C.c_uint32, [C.c_uint64]),
+    "vit_deflate_objects": (C.c_int, [vp, C.c_char_p, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp]),
+    "vit_deflate_out_bytes": (C.c_uint64, [vp, C.c_char_p, vp, C.c_uint64]),
     "vit_shard_plan": (C.c_int, [vp, C.c_uint64, C.c_int, vp]),
     "vit_host_split_plan": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp]),
     "vit_launch_shape": (C.c_int, [C.c_int, C.c_uint64, u32p, u32p]),

@@ -57,8 +57,9 @@ __global__ __launch_bounds__(64, OCC) void deflate_kernel(DeflateBatch b)
         for (uint32_t k = lane; k < 64u * zd::kHashSize * 2u / 16u; k += 64u) hd[k] = make_uint4(0, 0, 0, 0);
         __syncthreads();                                  // one wave: orders the lanes' stores before each other's loads
 
-        const uint64_t i = first + lane;
+        uint64_t i = first + lane;
         bool mine = i < b.n;
+        if (mine && b.order) { i = b.order[i]; if (i >= b.n) { atomicOr(b.status, STATUS_BAD_ORDER); mine = false; } }
         uint64_t off = 0, n = 0;
         uint32_t nb = 0;
         if (mine) {

@@ -82,6 +82,8 @@ struct Queue {
     void* sort_scratch = nullptr; size_t sort_scratch_bytes = 0;   // vit_bin_order_device
     uint8_t* z_workspace = nullptr; uint32_t z_lanes = 0;          // vit_deflate_arena_device: tables of the objects in flight
     void* z_tables = nullptr;                                      // ... and zlib's constant tables
+    uint8_t* z_out = nullptr; uint64_t z_out_cap = 0;              // vit_deflate_objects: a chunk's streams on the device
+    uint8_t* z_meta_d = nullptr; uint8_t* z_meta_h = nullptr; uint64_t z_meta_cap = 0;   // ... their offsets and lengths (12 bytes per object)
     std::vector<hipEvent_t> timing;                       // pool for vit_time_hash_device
     uint64_t* wave_trace = nullptr;                       // diagnostics: device buffer, 32 bytes per wave, that the next
                                                           // launches fill with their waves' timeline (tools/wave_timeline.py)
@@ -131,6 +133,7 @@ struct vit_hasher {
     double host_bias = 1;                                 // see the end of hash_batch
     uint64_t calibrate_ns = 0;
     uint64_t fail_at_chunk = 0;                           // fault injection for tests: 0 = off
+    uint64_t deflate_max_bytes = 16384;                   // vit_deflate_objects: longer objects (framed) are left to the host
     int deflate_occupancy = 4;                            // waves per SIMD the deflate kernel is compiled for (1, 2, 4, 8)
     uint32_t deflate_lanes = 65536;                       // objects the deflate kernel keeps in flight (176 KiB of device memory each)
     std::atomic<uint64_t> objects_gpu{0}, objects_host{0}, bytes_host{0}, blocks_gpu{0}, bytes_h2d{0}, launches{0};
@@ -828,6 +831,9 @@ void vit_hasher_destroy(vit_hasher* h)
         if (q.sort_scratch) (void)hipFree(q.sort_scratch);
         if (q.z_workspace) (void)hipFree(q.z_workspace);
         if (q.z_tables) (void)hipFree(q.z_tables);
+        if (q.z_out) (void)hipFree(q.z_out);
+        if (q.z_meta_d) (void)hipFree(q.z_meta_d);
+        if (q.z_meta_h) (void)hipHostFree(q.z_meta_h);
         for (hipEvent_t e : q.timing) (void)hipEventDestroy(e);
         for (hipStream_t st : q.stream) if (st) (void)hipStreamDestroy(st);
     }
@@ -865,6 +871,7 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     else if (k == "pack_rate") rate(h->pack_rate, h->pack_fixed);
     else if (k == "host_bias_percent") h->host_bias = value ? double(value) / 100.0 : 1.0;
     else if (k == "debug_fail_at_chunk") h->fail_at_chunk = value;
+    else if (k == "deflate_max_bytes") h->deflate_max_bytes = std::min<uint64_t>(value, vit::deflate_max_input());
     else if (k == "deflate_occupancy") h->deflate_occupancy = int(value);
     else if (k == "deflate_lanes") h->deflate_lanes = uint32_t(std::min<uint64_t>(std::max<uint64_t>(value, 64), 1u << 20) / 64 * 64);
     else if (k == "sched_waves") h->sched_waves = uint32_t(value > 8 ? 8 : value);
@@ -1331,7 +1338,7 @@ static int ensure_deflate(vit_hasher* h, Queue& q)
 }
 
 int vit_deflate_arena_device(vit_hasher* h, int dev, const void* d_arena, uint64_t arena_bytes, const uint64_t* d_offsets,
-                             const uint32_t* d_nblocks, uint64_t n, uint8_t* d_out, const uint64_t* d_out_offsets,
+                             const uint32_t* d_nblocks, const uint32_t* d_order, uint64_t n, uint8_t* d_out, const uint64_t* d_out_offsets,
                              uint32_t* d_out_lens, void* stream)
 {
     Queue* q = queue_of(h, dev);
@@ -1344,11 +1351,132 @@ int vit_deflate_arena_device(vit_hasher* h, int dev, const void* d_arena, uint64
     if (int rc = ensure_deflate(h, *q)) return rc;
     vit::DeflateBatch b;
     b.arena = static_cast<const uint8_t*>(d_arena); b.arena_bytes = arena_bytes;
-    b.offsets = d_offsets; b.nblocks = d_nblocks; b.n = uint32_t(n);
+    b.offsets = d_offsets; b.nblocks = d_nblocks; b.n = uint32_t(n); b.order = d_order;
     b.out = d_out; b.out_off = d_out_offsets; b.out_len = d_out_lens;
     b.workspace = q->z_workspace; b.tables_raw = q->z_tables; b.status = q->d_status;
     HIP_TRY(h, vit::launch_deflate(b, q->z_lanes, h->deflate_occupancy, stream ? static_cast<hipStream_t>(stream) : q->stream[0]));
     return VIT_OK;
+}
+
+// Objects from host memory: those of at most "deflate_max_bytes" (framed) are packed into the
+// queue's staging arena chunk by chunk, copied over, deflated by the kernel in order of length
+// and their streams copied back into `out`; the others get length 0 and are the caller's.  One
+// lane works through about 0.1 MB/s of input (a dependent chain of scattered table accesses per
+// byte), so the device is for the many small objects of a batch and host cores for the long ones.
+int vit_deflate_objects(vit_hasher* h, const char* type, const uint8_t* const* data, const uint64_t* len, uint64_t n,
+                        uint8_t* out, uint64_t out_cap, uint64_t* out_off, uint32_t* out_len)
+{
+    if (!h) return VIT_ERR_ARG;
+    const uint32_t tl = vit::type_len_checked(type);
+    if (!tl) return fail(h, VIT_ERR_ARG, "bad object type");
+    if (n == 0) return VIT_OK;
+    if (!data || !len || !out || !out_off || !out_len) return fail(h, VIT_ERR_ARG, "null argument");
+    if (n > 0xFFFFFFFFull) return fail(h, VIT_ERR_RANGE, "more than 2^32 - 1 objects in one call");
+    VIT_NOEXCEPT_BEGIN
+    Queue& q = h->queues[0];
+    drain(q);
+    HIP_TRY(h, hipSetDevice(q.device));
+    if (int rc = ensure_deflate(h, q)) return rc;
+
+    // which objects, their block counts, and where their streams go
+    std::vector<uint64_t> mine;
+    std::vector<uint32_t> nb(n, 0);
+    uint64_t total_out = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        out_len[i] = 0; out_off[i] = 0;
+        if (len[i] && !data[i]) return fail(h, VIT_ERR_ARG, "object %llu: null data with non-zero length", (unsigned long long)i);
+        const uint64_t framed = tl + 1 + vit::decimal_digits(len[i]) + 1 + len[i];
+        if (framed > h->deflate_max_bytes || framed > vit::deflate_max_input()) continue;
+        nb[i] = uint32_t((framed + 9 + 63) / 64);
+        out_off[i] = total_out;
+        total_out += (uint64_t(vit::deflate_bound(uint32_t(framed))) + 15) / 16 * 16;
+        mine.push_back(i);
+    }
+    if (total_out > out_cap) return fail(h, VIT_ERR_RANGE, "the streams may need %llu bytes, %llu given", (unsigned long long)total_out, (unsigned long long)out_cap);
+
+    constexpr uint64_t kChunkBytes = 256ull << 20;
+    Staging& s = q.st[0];
+    hipStream_t stream = q.stream[0];
+    for (size_t pos = 0; pos < mine.size();) {
+        uint64_t blocks = 0;
+        size_t end = pos;
+        while (end < mine.size() && (end == pos || (blocks + nb[mine[end]]) * 64 <= kChunkBytes)) blocks += nb[mine[end++]];
+        const uint64_t cnt = end - pos, bytes = blocks * 64;
+        const uint64_t out_lo = out_off[mine[pos]];
+        const uint64_t out_hi = end < mine.size() ? out_off[mine[end]] : total_out;
+        int rc;
+        if ((rc = ensure_arena(q, s, bytes)) || (rc = ensure_meta(q, s, cnt))) return fail(h, rc, "device queue 0: %s", q.err.c_str());
+        const uint64_t meta_bytes = carve_meta(s, cnt);
+        if (out_hi - out_lo > q.z_out_cap) {
+            if (q.z_out) { HIP_TRY(h, hipFree(q.z_out)); q.z_out = nullptr; q.z_out_cap = 0; }
+            const uint64_t cap = grown(q.z_out_cap, out_hi - out_lo);
+            HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&q.z_out), cap));
+            q.z_out_cap = cap;
+        }
+        if (cnt > q.z_meta_cap) {
+            if (q.z_meta_d) { HIP_TRY(h, hipFree(q.z_meta_d)); q.z_meta_d = nullptr; }
+            if (q.z_meta_h) { HIP_TRY(h, hipHostFree(q.z_meta_h)); q.z_meta_h = nullptr; }
+            const uint64_t cap = round_up(cnt, 65536);
+            HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&q.z_meta_d), cap * 12));
+            HIP_TRY(h, hipHostMalloc(reinterpret_cast<void**>(&q.z_meta_h), cap * 12, hipHostMallocDefault));
+            q.z_meta_cap = cap;
+        }
+        uint64_t* h_zoff = reinterpret_cast<uint64_t*>(q.z_meta_h);
+        uint32_t* h_zlen = reinterpret_cast<uint32_t*>(q.z_meta_h + q.z_meta_cap * 8);
+        uint64_t* d_zoff = reinterpret_cast<uint64_t*>(q.z_meta_d);
+        uint32_t* d_zlen = reinterpret_cast<uint32_t*>(q.z_meta_d + q.z_meta_cap * 8);
+
+        std::vector<uint64_t> prefix(cnt + 1, 0);
+        for (uint64_t k = 0; k < cnt; ++k) {
+            const uint64_t i = mine[pos + k];
+            s.h_off[k] = prefix[k] * 64;
+            s.h_nb[k] = nb[i];
+            prefix[k + 1] = prefix[k] + nb[i];
+            h_zoff[k] = out_off[i] - out_lo;
+        }
+        const uint64_t pieces = std::min<uint64_t>({cnt, std::max<uint64_t>(bytes / (2u << 20), 1), uint64_t(h->pack_threads) * 4});
+        const std::vector<uint64_t> cut = vit::balanced_cuts(cnt, int(pieces), prefix.data());
+        h->pool->run(vit::WorkPool::HIGH, size_t(pieces), [&](size_t p) {
+            for (uint64_t k = cut[p]; k < cut[p + 1]; ++k) {
+                const uint64_t i = mine[pos + k];
+                vit::pack_one(type, tl, data[i], len[i], s.h_arena + s.h_off[k], s.h_nb[k]);
+            }
+            vit::pack_fence();
+        });
+        const bool binned = vit::bin_order(s.h_nb, cnt, s.h_order);
+        HIP_TRY(h, hipMemcpyAsync(s.d_arena, s.h_arena, bytes, hipMemcpyHostToDevice, stream));
+        HIP_TRY(h, hipMemcpyAsync(s.d_meta, s.h_meta, meta_bytes + (binned ? meta_bytes / 3 : 0), hipMemcpyHostToDevice, stream));
+        HIP_TRY(h, hipMemcpyAsync(d_zoff, h_zoff, cnt * 8, hipMemcpyHostToDevice, stream));
+        vit::DeflateBatch b;
+        b.arena = s.d_arena; b.arena_bytes = bytes; b.offsets = s.d_off; b.nblocks = s.d_nb; b.n = uint32_t(cnt);
+        b.order = binned ? s.d_order : nullptr;
+        b.out = q.z_out; b.out_off = d_zoff; b.out_len = d_zlen;
+        b.workspace = q.z_workspace; b.tables_raw = q.z_tables; b.status = q.d_status;
+        HIP_TRY(h, vit::launch_deflate(b, q.z_lanes, h->deflate_occupancy, stream));
+        HIP_TRY(h, hipMemcpyAsync(out + out_lo, q.z_out, out_hi - out_lo, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(h, hipMemcpyAsync(h_zlen, d_zlen, cnt * 4, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(h, hipStreamSynchronize(stream));
+        for (uint64_t k = 0; k < cnt; ++k) out_len[mine[pos + k]] = h_zlen[k];
+        pos = end;
+    }
+    uint32_t word = 0;
+    if (int rc = read_status_word(h, q, &word)) return rc;
+    if (word) return fail(h, VIT_ERR_DEVICE_STATUS, "device queue 0 flagged status %u", word);
+    return VIT_OK;
+    VIT_NOEXCEPT_END(h)
+}
+
+uint64_t vit_deflate_out_bytes(const vit_hasher* h, const char* type, const uint64_t* len, uint64_t n)
+{
+    const uint32_t tl = vit::type_len_checked(type);
+    if (!h || !tl || (n && !len)) return 0;
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t framed = tl + 1 + vit::decimal_digits(len[i]) + 1 + len[i];
+        if (framed > h->deflate_max_bytes || framed > vit::deflate_max_input()) continue;
+        total += (uint64_t(vit::deflate_bound(uint32_t(framed))) + 15) / 16 * 16;
+    }
+    return total;
 }
 
 uint32_t vit_deflate_bound(uint64_t framed_len)

@@ -123,6 +123,7 @@ hipError_t device_simds(uint32_t* out);
 struct DeflateBatch {
     const uint8_t*  arena; uint64_t arena_bytes;
     const uint64_t* offsets; const uint32_t* nblocks; uint32_t n;
+    const uint32_t* order;        // optional: slot s deflates object order[s] (objects sorted by length, so that a wave's 64 end together)
     uint8_t*        out; const uint64_t* out_off; uint32_t* out_len;
     uint8_t*        workspace;
     const void*     tables_raw;   // device copy of what deflate_make_tables() wrote

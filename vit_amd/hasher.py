@@ -268,7 +268,7 @@ class Hasher:
         self.sync(batch["dev"])
         return batch["digests"].download(np.uint8, 20 * batch["n"]).reshape(-1, 20)
 
-    def deflate_device(self, batch, framed_lens):
+    def deflate_device(self, batch, framed_lens, order=None):
         """zlib streams of a batch from synth_arena() (vit_deflate_arena_device).  framed_lens: header + content
         length per object (sizes the output).  Returns (list of bytes, seconds on the device)."""
         import time
@@ -283,13 +283,30 @@ class Hasher:
         self.sync(batch["dev"])
         t0 = time.perf_counter()
         self._check(lib.vit_deflate_arena_device(self.handle, batch["dev"], batch["arena"].ptr, batch["arena_bytes"],
-                                                 batch["offsets"].ptr, batch["nblocks"].ptr, n, d_out.ptr, d_off.ptr,
+                                                 batch["offsets"].ptr, batch["nblocks"].ptr,
+                                                 order.ptr if order is not None else None, n, d_out.ptr, d_off.ptr,
                                                  d_len.ptr, None))
         self.sync(batch["dev"])
         dt = time.perf_counter() - t0
         lens = d_len.download(np.uint32, 4 * n)
         raw = d_out.download(np.uint8, int(off[-1]))
         return [raw[int(off[i]):int(off[i]) + int(lens[i])].tobytes() for i in range(n)], dt
+
+    def deflate_objects(self, type_, blobs):
+        """zlib streams of objects in host memory (vit_deflate_objects).  Returns (list of bytes, b'' where the
+        object was left to the caller; seconds inside the call)."""
+        import time
+        keep, ptrs, lens = _as_ptr_arrays(blobs)
+        n = len(blobs)
+        need = self.lib.vit_deflate_out_bytes(self.handle, type_.encode(), lens.ctypes.data, n)
+        out = np.zeros(max(need, 16), dtype=np.uint8)
+        off = np.zeros(max(n, 1), dtype=np.uint64)
+        zl = np.zeros(max(n, 1), dtype=np.uint32)
+        t0 = time.perf_counter()
+        self._check(self.lib.vit_deflate_objects(self.handle, type_.encode(), ptrs, lens.ctypes.data, n, out.ctypes.data,
+                                                 out.size, off.ctypes.data, zl.ctypes.data))
+        dt = time.perf_counter() - t0
+        return [out[int(off[i]):int(off[i]) + int(zl[i])].tobytes() for i in range(n)], dt
 
     def time_hash_device(self, batch, order=None, warmup=1, iters=5):
         ms = (C.c_float * max(iters, 1))()
