@@ -48,6 +48,7 @@ __global__ __launch_bounds__(64, OCC) void deflate_kernel(DeflateBatch b)
     w.d_buf = zd::Arr16{dbuf16 + lane, 64};
     w.l_buf = zd::Arr8{lbuf8 + lane, 64};
     w.small = small16 + lane;
+    w.heap = reinterpret_cast<uint32_t*>(small16 + 64u * zd::kSmallEntries) + lane;
     w.small_stride = 64;
     zd::Deflater<ArenaBytes> d;
 

@@ -14,6 +14,9 @@
 #include <cstring>
 #include <filesystem>
 #include <fstream>
+#include <future>
+#include <deque>
+#include <condition_variable>
 #include <iostream>
 #include <mutex>
 #include <queue>
@@ -137,15 +140,17 @@ bool deflateFramed(int level, const std::string& type, const std::string& conten
 }
 
 // Write atomically: a reader (or a crash) never sees a half-written object.
-bool writeFileAtomic(const std::string& path, const std::string& bytes)
+bool writeFileAtomic(const std::string& path, const char* data, size_t size);
+bool writeFileAtomic(const std::string& path, const std::string& bytes) { return writeFileAtomic(path, bytes.data(), bytes.size()); }
+bool writeFileAtomic(const std::string& path, const char* data, size_t size)
 {
     static std::atomic<uint64_t> serial{0};
     const std::string tmp = path + ".tmp" + std::to_string(uint64_t(getpid())) + "_" + std::to_string(serial++);
     const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
     if (fd < 0) return false;
     size_t put = 0;
-    while (put < bytes.size()) {
-        const ssize_t w = ::write(fd, bytes.data() + put, bytes.size() - put);
+    while (put < size) {
+        const ssize_t w = ::write(fd, data + put, size - put);
         if (w < 0 && errno == EINTR) continue;
         if (w <= 0) { ::close(fd); ::unlink(tmp.c_str()); return false; }
         put += size_t(w);
@@ -299,6 +304,47 @@ bool walk(const std::string& root, vit::WorkPool& pool, bool git_rules, std::vec
     return true;
 }
 
+// One thread that runs what it is given, in order.  (The device deflate of successive batches: its
+// hasher serves one caller at a time, and a batch's stores are queued when its streams are there.)
+class SerialWorker {
+public:
+    SerialWorker() : t_([this] { loop(); }) {}
+    ~SerialWorker()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        t_.join();
+    }
+    std::shared_future<void> post(std::function<void()> f)
+    {
+        std::packaged_task<void()> task(std::move(f));
+        std::shared_future<void> done = task.get_future().share();
+        { std::lock_guard<std::mutex> lk(m_); q_.push_back(std::move(task)); }
+        cv_.notify_one();
+        return done;
+    }
+private:
+    void loop()
+    {
+        for (;;) {
+            std::packaged_task<void()> task;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [this] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;                    // stop asked for and nothing left
+                task = std::move(q_.front());
+                q_.pop_front();
+            }
+            task();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<std::packaged_task<void()>> q_;
+    bool stop_ = false;
+    std::thread t_;
+};
+
 }  // namespace
 
 namespace vit {
@@ -309,11 +355,13 @@ ObjectStore::ObjectStore(std::string objects_dir, std::vector<int> devices)
     unsigned hw = std::thread::hardware_concurrency();
     io_threads_ = int(hw ? std::min(hw, 16u) : 4);
     if (const char* e = std::getenv("VIT_DEFLATE_LEVEL")) setDeflateLevel(std::atoi(e));
+    if (const char* e = std::getenv("VIT_DEVICE_DEFLATE")) setDeviceDeflate(std::atoi(e) != 0);
 }
 
 ObjectStore::~ObjectStore()
 {
     pool_.reset();
+    if (deflate_hasher_) vit_hasher_destroy(deflate_hasher_);
     if (hasher_) vit_hasher_destroy(hasher_);
 }
 
@@ -336,6 +384,24 @@ bool ObjectStore::ensureHasher()
     // The store's own pool (reads, deflate, writes) keeps the cores busy while a
     // batch is hashed: the hasher's packing threads get a modest share.
     vit_hasher_set_option(hasher_, "pack_threads", uint64_t(std::max(2, io_threads_ / 2)));
+    return true;
+}
+
+// A second hasher on the same device for the deflate kernel: its own streams and staging memory, so that a
+// thread of its own can make the streams of one batch while this one hashes the next.
+bool ObjectStore::ensureDeflateHasher()
+{
+    if (deflate_hasher_) return true;
+    if (deflate_hasher_failed_) return false;
+    const int dev = devices_.empty() ? 0 : devices_[0];
+    if (vit_hasher_create(&dev, 1, &deflate_hasher_) != VIT_OK) {
+        std::cerr << "vit: no second hasher for the device deflate (" << vit_last_error(nullptr) << "); deflating on host threads\n";
+        deflate_hasher_ = nullptr;
+        deflate_hasher_failed_ = true;
+        return false;
+    }
+    vit_hasher_set_option(deflate_hasher_, "pack_threads", uint64_t(std::max(2, io_threads_ / 4)));
+    if (const char* e = std::getenv("VIT_DEVICE_DEFLATE_MAX")) vit_hasher_set_option(deflate_hasher_, "deflate_max_bytes", std::strtoull(e, nullptr, 10));
     return true;
 }
 
@@ -396,7 +462,7 @@ static bool alreadyStored(const std::string& path)
 // must stay alive until the ticket has been waited for.  Low priority: file
 // reads of the next batch, which feed the GPU, go first.
 WorkPool::Ticket ObjectStore::storeAsync(const std::string& type, const std::vector<std::string>& contents,
-                                         const std::vector<uint8_t>& raw, StoreOutcome& outcome)
+                                         const std::vector<uint8_t>& raw, StoreOutcome& outcome, DeviceStreams dz)
 {
     const size_t n = contents.size();
     bool need[256] = {false};                             // the "aa" fan-out directories this batch touches
@@ -411,11 +477,15 @@ WorkPool::Ticket ObjectStore::storeAsync(const std::string& type, const std::vec
     const std::string* c = contents.data();
     const uint8_t* r = raw.data();
     const int level = deflate_level_;
-    return pool().submit(WorkPool::LOW, slices, [this, type, c, r, n, slices, level, &outcome](size_t s) {
+    return pool().submit(WorkPool::LOW, slices, [this, type, c, r, n, slices, level, dz, &outcome](size_t s) {
         for (size_t i = n * s / slices; i < n * (s + 1) / slices; ++i) {
             try {
                 const std::string path = objectPath(toHex(r + i * 20, 20));
                 if (skip_existing_ && alreadyStored(path)) { ++outcome.skipped; continue; }
+                if (dz.buf && dz.len[i]) {                 // the device has made this object's stream already
+                    if (!writeFileAtomic(path, reinterpret_cast<const char*>(dz.buf + dz.off[i]), dz.len[i])) outcome.failed = 2;
+                    continue;
+                }
                 std::string z;
                 if (!deflateFramed(level, type, c[i], z)) { outcome.failed = 1; continue; }
                 if (!writeFileAtomic(path, z)) outcome.failed = 2;
@@ -454,7 +524,7 @@ std::vector<std::string> ObjectStore::writeObjects(const std::string& type, cons
     if (store_) {
         const auto t1 = clk::now();
         StoreOutcome outcome;
-        pool().wait(storeAsync(type, contents, raw, outcome));
+        pool().wait(storeAsync(type, contents, raw, outcome, DeviceStreams{nullptr, nullptr, nullptr}));
         stats_.deflate_store_s += since(t1);
         if (!storeFinished(outcome)) return {};
     }
@@ -488,29 +558,50 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
     //   ids of batch k on the GPU (this thread; packing on the hasher's threads)
     //   deflate + store of batches k-1, k (pool, low priority: by far the most work)
     // A batch's contents live in one of three slots until its objects are stored.
+    const bool on_device = device_deflate_ && store_ && (deflate_level_ == -1 || deflate_level_ == 6) && ensureDeflateHasher();
+    // With the device deflating there is a fourth stage (streams of batch k on the GPU, through a hasher and a
+    // thread of its own, while this thread reads and hashes batch k+1), hence a fourth slot; and the deflate kernel
+    // wants tens of thousands of objects per launch: fewer, larger batches.
+    const size_t ns = on_device ? 4 : 3;
+    uint64_t batch_bytes = on_device ? std::max<uint64_t>(batch_bytes_, 512ull << 20) : batch_bytes_;
+    if (const char* e = std::getenv("VIT_BATCH_MB")) batch_bytes = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)) << 20;
     struct Slot {
         std::vector<std::string> contents;
         std::vector<uint8_t> raw;
         WorkPool::Ticket read, store;
+        std::shared_future<void> deflate;                 // device deflate of the batch; queues the batch's stores when done
         StoreOutcome outcome;
-    } slot[3];
+        void* zbuf = nullptr; uint64_t zcap = 0;          // pinned: the streams the device made for this batch
+        std::vector<uint64_t> zoff; std::vector<uint32_t> zlen;
+    } slot[4];
+    struct FreePinned {                                   // on every way out
+        vit_hasher* h; Slot* s;
+        ~FreePinned() { for (int k = 0; k < 4; ++k) if (s[k].zbuf) vit_arena_free(h, s[k].zbuf); }
+    } free_pinned{hasher_, slot};
+    std::unique_ptr<SerialWorker> deflater;               // after the slots: joined before they go
+    if (on_device) deflater.reset(new SerialWorker());
     std::vector<std::pair<size_t, size_t>> batches;
     for (size_t pos = 0; pos < files.size();) {
         size_t end = pos;
         uint64_t bytes = 0;
-        while (end < files.size() && (end == pos || bytes + files[end].size <= batch_bytes_)) bytes += files[end++].size;
+        while (end < files.size() && (end == pos || bytes + files[end].size <= batch_bytes)) bytes += files[end++].size;
         batches.emplace_back(pos, end);
         pos = end;
     }
     bool ok = true;
+    const bool timeline = std::getenv("VIT_TIMELINE") != nullptr;   // diagnostics: when each stage of each batch ended
+    auto mark = [&, t_all](const char* what, size_t k) {
+        if (timeline) std::fprintf(stderr, "[vit timeline] %8.1f ms  batch %zu %s\n", since(t_all) * 1e3, k, what);
+    };
     auto finish = [&](Slot& s) {                          // wait for a slot's stores; false if any failed
+        if (s.deflate.valid()) { s.deflate.wait(); s.deflate = std::shared_future<void>(); }
         if (!s.store) return true;
         workers.wait(s.store);
         s.store.reset();
         return storeFinished(s.outcome);
     };
     auto start_read = [&](size_t k) {
-        Slot& s = slot[k % 3];
+        Slot& s = slot[k % ns];
         const size_t pos = batches[k].first, cnt = batches[k].second - pos;
         s.contents.assign(cnt, std::string());
         std::string* out = s.contents.data();
@@ -532,27 +623,63 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
     const auto t_store = clk::now();
     if (!batches.empty()) start_read(0);
     for (size_t k = 0; k < batches.size() && ok; ++k) {
-        Slot& s = slot[k % 3];
+        Slot& s = slot[k % ns];
         if (k + 1 < batches.size()) {
-            ok = finish(slot[(k + 1) % 3]);               // batch k-2 used that slot: its objects must be on disk
+            ok = finish(slot[(k + 1) % ns]);
+            mark("slot free for the read of the next", k);               // batch k-2 used that slot: its objects must be on disk
             if (!ok) break;
             start_read(k + 1);
         }
         t0 = clk::now();
         workers.wait(s.read);
         stats_.read_s += since(t0);
+        mark("read", k);
         t0 = clk::now();
         std::vector<const std::string*> view(s.contents.size());
         for (size_t i = 0; i < view.size(); ++i) view[i] = &s.contents[i];
         if (!hashObjects("blob", view, s.raw)) { ok = false; break; }
         stats_.hash_s += since(t0);
+        mark("hashed", k);
         const size_t pos = batches[k].first;
         for (size_t i = 0; i < s.contents.size(); ++i) {
             std::memcpy(files[pos + i].id, &s.raw[i * 20], 20);
             stats_.bytes += s.contents[i].size();
         }
         stats_.blobs += s.contents.size();
-        if (store_) s.store = storeAsync("blob", s.contents, s.raw, s.outcome);
+        if (on_device) {
+            Slot* sp = &s;
+            s.deflate = deflater->post([this, sp, k, &mark] {
+                Slot& s = *sp;
+                mark("deflate begins", k);
+                DeviceStreams dz{nullptr, nullptr, nullptr};
+                try {
+                    const auto t = clk::now();
+                    const size_t cnt = s.contents.size();
+                    std::vector<const uint8_t*> ptr(cnt);
+                    std::vector<uint64_t> len(cnt);
+                    for (size_t i = 0; i < cnt; ++i) { ptr[i] = reinterpret_cast<const uint8_t*>(s.contents[i].data()); len[i] = s.contents[i].size(); }
+                    const uint64_t need = vit_deflate_out_bytes(deflate_hasher_, "blob", len.data(), cnt);
+                    if (need > s.zcap) {
+                        if (s.zbuf) { vit_arena_free(hasher_, s.zbuf); s.zbuf = nullptr; s.zcap = 0; }
+                        if (vit_arena_alloc(hasher_, need + need / 4, &s.zbuf) == VIT_OK) s.zcap = need + need / 4;
+                    }
+                    s.zoff.assign(cnt, 0); s.zlen.assign(cnt, 0);
+                    if (need && s.zbuf &&
+                        vit_deflate_objects(deflate_hasher_, "blob", ptr.data(), len.data(), cnt, static_cast<uint8_t*>(s.zbuf), s.zcap,
+                                            s.zoff.data(), s.zlen.data()) == VIT_OK) {
+                        dz = DeviceStreams{static_cast<const uint8_t*>(s.zbuf), s.zoff.data(), s.zlen.data()};
+                        for (uint32_t l : s.zlen) stats_.device_deflated += l != 0;
+                    } else if (need) {
+                        std::cerr << "vit: deflate on the device failed (" << vit_last_error(deflate_hasher_) << "); this batch on host threads\n";
+                    }
+                    stats_.device_deflate_s += since(t);
+                } catch (const std::exception&) { dz = DeviceStreams{nullptr, nullptr, nullptr}; }      // out of memory: host threads do the batch
+                mark("deflated", k);
+                s.store = storeAsync("blob", s.contents, s.raw, s.outcome, dz);
+            });
+        } else if (store_) {
+            s.store = storeAsync("blob", s.contents, s.raw, s.outcome, DeviceStreams{nullptr, nullptr, nullptr});
+        }
     }
     for (Slot& s : slot) {                                // also on failure: no job may outlive the slots
         if (s.read) workers.wait(s.read);

@@ -33,11 +33,11 @@ struct TreeEntry {
 namespace vit {
 
 struct StoreStats {
-    uint64_t blobs = 0, trees = 0, bytes = 0;
+    uint64_t device_deflated = 0, blobs = 0, trees = 0, bytes = 0;
     uint64_t skipped = 0;                      // objects already in the store (not deflated or written again)
     // writeTree overlaps its stages: read_s = what the hashing thread waited for file reads, hash_s = GPU batches
     // (pack + copy + kernel + read-back), deflate_store_s = from the first batch's hand-over to the last object on disk
-    double init_s = 0, walk_s = 0, read_s = 0, hash_s = 0, deflate_store_s = 0, trees_s = 0, tree_hash_s = 0, total_s = 0;
+    double init_s = 0, walk_s = 0, read_s = 0, hash_s = 0, device_deflate_s = 0, deflate_store_s = 0, trees_s = 0, tree_hash_s = 0, total_s = 0;
 };
 
 class ObjectStore {
@@ -89,6 +89,10 @@ public:
     // reference's in their bytes but hold the same object (they inflate to the same "<type> <len>\0" + content, so the
     // reference's readObject and git read them); level 1 deflates about three times faster, level 0 stores.
     void setDeflateLevel(int level) { deflate_level_ = level < -1 ? -1 : (level > 9 ? 9 : level); }
+    // Where the small objects of a write-tree are deflated.  true: on the GPU, by the kernel that writes the zlib
+    // library's own bytes (vit_deflate_objects; objects above its size limit still go to host threads), so that the
+    // host threads are left with creating files.  Only at the default level: any other level is the host's.
+    void setDeviceDeflate(bool on) { device_deflate_ = on; }
     void setIoThreads(int n) { io_threads_ = n < 1 ? 1 : n; }
     void setBatchBytes(uint64_t b) { batch_bytes_ = b < 1 ? 1 : b; }
     const StoreStats& lastStats() const { return stats_; }
@@ -98,10 +102,13 @@ public:
 private:
     struct StoreOutcome { std::atomic<int> failed{0}; std::atomic<uint64_t> skipped{0}; };   // 1 compression, 2 write
     bool ensureHasher();
+    bool ensureDeflateHasher();
     void tuneHasher();                                   // per call: which objects may leave the GPU for host threads
     WorkPool& pool();
+    // Streams made on the device for a batch: stream i = buf[off[i] .. off[i] + len[i]); len[i] == 0: none.
+    struct DeviceStreams { const uint8_t* buf; const uint64_t* off; const uint32_t* len; };
     WorkPool::Ticket storeAsync(const std::string& type, const std::vector<std::string>& contents,
-                                const std::vector<uint8_t>& raw, StoreOutcome& outcome);
+                                const std::vector<uint8_t>& raw, StoreOutcome& outcome, DeviceStreams z);
     bool storeFinished(StoreOutcome& outcome);
 
     std::string objects_dir_;
@@ -109,10 +116,13 @@ private:
     std::unique_ptr<WorkPool> pool_;
     bool hasher_failed_ = false;
     vit_hasher* hasher_ = nullptr;
+    vit_hasher* deflate_hasher_ = nullptr;                // second set of streams and staging, for the device deflate
+    bool deflate_hasher_failed_ = false;
     bool store_ = true;
     bool skip_existing_ = true;
     bool git_rules_ = false;
     int deflate_level_ = -1;
+    bool device_deflate_ = false;
     int io_threads_ = 8;
     // Blobs per hashing batch, by bytes.  128 MiB: a dozen or more batches on a worktree of gigabytes, so that
     // reading, hashing and storing overlap, and three batches of contents in memory at most.

@@ -77,6 +77,8 @@ bool cmdWriteTree(int argc, char** argv)
         else if (!std::strcmp(argv[i], "--no-store")) vit::defaultStore().setStoreObjects(false);
         else if (!std::strcmp(argv[i], "--rewrite")) vit::defaultStore().setSkipExisting(false);
         else if (!std::strcmp(argv[i], "--git-order")) vit::defaultStore().setGitTreeRules(true);
+        else if (!std::strcmp(argv[i], "--device-deflate")) vit::defaultStore().setDeviceDeflate(true);
+        else if (!std::strcmp(argv[i], "--host-deflate")) vit::defaultStore().setDeviceDeflate(false);
         else if (!std::strncmp(argv[i], "--deflate-level=", 16)) vit::defaultStore().setDeflateLevel(std::atoi(argv[i] + 16));
         else { std::cerr << "Unknown flag: " << argv[i] << '\n'; return false; }
     }
@@ -87,7 +89,8 @@ bool cmdWriteTree(int argc, char** argv)
         const vit::StoreStats& s = vit::defaultStore().lastStats();
         std::cerr << "blobs " << s.blobs << " trees " << s.trees << " bytes " << s.bytes << " already-stored " << s.skipped
                   << " | init " << s.init_s << " s walk " << s.walk_s
-                  << " s read-wait " << s.read_s << " s hash " << s.hash_s << " s blobs-pipeline(read|hash|deflate+store) " << s.deflate_store_s
+                  << " s read-wait " << s.read_s << " s hash " << s.hash_s << " s device-deflate " << s.device_deflate_s << " s (" << s.device_deflated
+                  << " objects) blobs-pipeline(read|hash|deflate+store) " << s.deflate_store_s
                   << " s trees(ids+deflate+store, level by level) " << s.trees_s << " s of which ids " << s.tree_hash_s
                   << " s total " << s.total_s << " s\n";
     }

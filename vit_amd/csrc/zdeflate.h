@@ -105,6 +105,10 @@ struct Arr16 {
     uint16_t* p; uint32_t stride;
     ZD_FN uint16_t& operator[](int i) const { return p[uint32_t(i) * stride]; }
 };
+struct Arr32 {
+    uint32_t* p; uint32_t stride;
+    ZD_FN uint32_t& operator[](int i) const { return p[uint32_t(i) * stride]; }
+};
 struct Arr8 {
     uint8_t* p; uint32_t stride;
     ZD_FN uint8_t& operator[](int i) const { return p[uint32_t(i) * stride]; }
@@ -112,7 +116,8 @@ struct Arr8 {
 
 // Entries of the small arrays, in this order, in Work::small.
 constexpr int kLtN = kHeapSize, kDtN = 2 * kDCodes + 1, kBtN = 2 * kBLCodes + 1;
-constexpr int kSmallEntries = 2 * kLtN + 2 * kDtN + 2 * kBtN + kHeapSize /*heap*/ + kHeapSize /*depth*/ + 16 /*bl_count*/ + 16 /*next_code*/;
+constexpr int kSmallEntries = 2 * kLtN + 2 * kDtN + 2 * kBtN + 16 /*bl_count*/ + 16 /*next_code*/;   // 16-bit entries
+constexpr int kHeapEntries = kHeapSize;                                                             // 32-bit entries
 
 // Per-object workspace.  head must be all zero on entry (the caller clears it); the other
 // arrays need no initialisation.
@@ -121,14 +126,15 @@ struct Work {
     Arr16 prev;                              // 32768 entries
     Arr16 d_buf;                             // kLitBufSize entries: match distances (0 = literal)
     Arr8  l_buf;                             // kLitBufSize entries: literals / match lengths - 3
-    uint16_t* small;                         // kSmallEntries entries, `small_stride` apart: the trees, heap, counts
+    uint16_t* small;                         // kSmallEntries entries, `small_stride` apart: the trees and counts
+    uint32_t* heap;                          // kHeapEntries entries, `small_stride` apart
     uint32_t  small_stride;
     uint8_t*  out;                           // the stream; capacity out_cap
     uint32_t  out_cap;
 };
 
 constexpr uint32_t work_bytes() { return kHashSize * 2 + 32768 * 2 + kLitBufSize * 2 + kLitBufSize; }
-constexpr uint32_t small_bytes() { return kSmallEntries * 2; }
+constexpr uint32_t small_bytes() { return kSmallEntries * 2 + kHeapEntries * 4; }
 // What compress() itself asks for (compressBound): enough for any input, stored blocks included.
 ZD_FN uint32_t bound(uint32_t n) { return n + (n >> 12) + (n >> 14) + (n >> 25) + 13; }
 
@@ -139,7 +145,11 @@ struct State {
     Work w;
     uint32_t n;                              // input bytes
     Arr16 lt_fc, lt_dl, dt_fc, dt_dl, bt_fc, bt_dl;   // literal/length tree (573 nodes: 286 leaves + internal), distance, bit-length
-    Arr16 heap, depth, bl_count, next_code;
+    // The heap of build_tree holds, per entry, a node with its sort key: frequency << 16 | depth << 10 | node (a block
+    // has at most 16384 symbols and a tree over them at most 23 levels, so 15 + 6 + 10 bits do), which makes a
+    // comparison one load per side instead of three (trees.c keeps node numbers and looks Freq and depth up).
+    Arr32 heap;
+    Arr16 bl_count, next_code;
     int l_max_code, d_max_code;
     int heap_len, heap_max;
     uint32_t opt_len, static_len;
@@ -195,21 +205,20 @@ template <class In> struct Deflater {
         s.last_lit = 0;
     }
 
-    ZD_FN static bool smaller(const Arr16& fc, const Arr16& depth, int n, int m)
+    // smaller(tree, n, m, depth) of trees.c on packed entries: lower frequency first, ties by lower depth, equal keys either way
+    ZD_FN static bool smaller(uint32_t a, uint32_t b) { return (a >> 10) <= (b >> 10); }
+    ZD_FN void pqdownheap(int k)
     {
-        return fc[n] < fc[m] || (fc[n] == fc[m] && depth[n] <= depth[m]);
-    }
-    ZD_FN void pqdownheap(const Arr16& fc, int k)
-    {
-        const int v = s.heap[k];
+        const uint32_t v = s.heap[k];
         int j = k << 1;
         while (j <= s.heap_len) {
-            if (j < s.heap_len && smaller(fc, s.depth, s.heap[j + 1], s.heap[j])) j++;
-            if (smaller(fc, s.depth, v, s.heap[j])) break;
-            { const uint16_t hj = s.heap[j]; s.heap[k] = hj; } k = j;
+            uint32_t hj = s.heap[j];
+            if (j < s.heap_len) { const uint32_t hj1 = s.heap[j + 1]; if (smaller(hj1, hj)) { hj = hj1; j++; } }
+            if (smaller(v, hj)) break;
+            s.heap[k] = hj; k = j;
             j <<= 1;
         }
-        s.heap[k] = uint16_t(v);
+        s.heap[k] = v;
     }
 
     // which: 0 literal/length, 1 distance, 2 bit-length tree
@@ -220,9 +229,9 @@ template <class In> struct Deflater {
         const int max_length = which == 2 ? kMaxBLBits : kMaxBits;
         int h, n, m, bits, xbits, overflow = 0;
         for (bits = 0; bits <= kMaxBits; bits++) s.bl_count[bits] = 0;
-        dl[s.heap[s.heap_max]] = 0;
+        dl[int(s.heap[s.heap_max] & 1023u)] = 0;
         for (h = s.heap_max + 1; h < kHeapSize; h++) {
-            n = s.heap[h];
+            n = int(s.heap[h] & 1023u);
             bits = dl[dl[n]] + 1;
             if (bits > max_length) { bits = max_length; overflow++; }
             dl[n] = uint16_t(bits);
@@ -247,7 +256,7 @@ template <class In> struct Deflater {
         for (bits = max_length; bits != 0; bits--) {
             n = s.bl_count[bits];
             while (n != 0) {
-                m = s.heap[--h];
+                m = int(s.heap[--h] & 1023u);
                 if (m > max_code) continue;
                 if (unsigned(dl[m]) != unsigned(bits)) {
                     s.opt_len += (uint32_t(bits) - uint32_t(dl[m])) * uint32_t(fc[m]);
@@ -278,34 +287,37 @@ template <class In> struct Deflater {
         int n, m, max_code = -1, node;
         s.heap_len = 0; s.heap_max = kHeapSize;
         for (n = 0; n < elems; n++) {
-            if (fc[n] != 0) { max_code = n; s.heap[++s.heap_len] = uint16_t(n); s.depth[n] = 0; }
+            const uint32_t f = fc[n];
+            if (f != 0) { max_code = n; s.heap[++s.heap_len] = (f << 16) | uint32_t(n); }
             else dl[n] = 0;
         }
         while (s.heap_len < 2) {
             node = (max_code < 2 ? ++max_code : 0);
-            s.heap[++s.heap_len] = uint16_t(node);
+            s.heap[++s.heap_len] = (1u << 16) | uint32_t(node);
             fc[node] = 1;
-            s.depth[node] = 0;
             s.opt_len--;
             if (which == 0) s.static_len -= s.t->static_llen[node];
             else if (which == 1) s.static_len -= 5;
         }
-        for (n = s.heap_len / 2; n >= 1; n--) pqdownheap(fc, n);
+        for (n = s.heap_len / 2; n >= 1; n--) pqdownheap(n);
         node = elems;
         do {
-            n = s.heap[1];
+            const uint32_t en = s.heap[1];
             s.heap[1] = s.heap[s.heap_len]; s.heap_len--;
-            pqdownheap(fc, 1);
-            m = s.heap[1];
-            s.heap[--s.heap_max] = uint16_t(n);
-            s.heap[--s.heap_max] = uint16_t(m);
-            fc[node] = uint16_t(fc[n] + fc[m]);
-            s.depth[node] = uint16_t((s.depth[n] >= s.depth[m] ? s.depth[n] : s.depth[m]) + 1);
+            pqdownheap(1);
+            const uint32_t em = s.heap[1];
+            s.heap[--s.heap_max] = en;
+            s.heap[--s.heap_max] = em;
+            n = int(en & 1023u); m = int(em & 1023u);
+            const uint32_t dn = (en >> 10) & 63u, dm = (em >> 10) & 63u;
+            const uint32_t f = (en >> 16) + (em >> 16);
+            fc[node] = uint16_t(f);
             dl[n] = dl[m] = uint16_t(node);
-            s.heap[1] = uint16_t(node); node++;
-            pqdownheap(fc, 1);
+            s.heap[1] = (f << 16) | (((dn >= dm ? dn : dm) + 1u) << 10) | uint32_t(node);
+            node++;
+            pqdownheap(1);
         } while (s.heap_len >= 2);
-        { const uint16_t top = s.heap[1]; s.heap[--s.heap_max] = top; }
+        { const uint32_t top = s.heap[1]; s.heap[--s.heap_max] = top; }
         gen_bitlen(fc, dl, max_code, which);
         gen_codes(fc, dl, max_code);
         return max_code;
@@ -440,8 +452,8 @@ template <class In> struct Deflater {
             s.lt_fc = take(kLtN); s.lt_dl = take(kLtN);
             s.dt_fc = take(kDtN); s.dt_dl = take(kDtN);
             s.bt_fc = take(kBtN); s.bt_dl = take(kBtN);
-            s.heap = take(kHeapSize); s.depth = take(kHeapSize);
             s.bl_count = take(16); s.next_code = take(16);
+            s.heap = Arr32{work.heap, st};
         }
         init_block();
         put_byte(0x78); put_byte(0x9c);                                   // deflate, 32 KiB window, default level
