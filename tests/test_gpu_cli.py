@@ -77,6 +77,33 @@ def test_stored_objects_are_byte_identical_to_the_oracles(oracle, golden_trees, 
     assert n >= len(golden_trees["nested_names"]["tree_ids"]) + len(golden_trees["nested_names"]["blob_ids"])
 
 
+def test_device_deflate_stores_the_files_the_library_would(oracle, golden_trees, worktrees, tmp_path):
+    """The streams the GPU lanes write (forced onto small batches here; by default only batches of 16384 small objects
+    and more take that way) are the zlib library's: every loose-object file of a worktree equals the oracle's, for the
+    10,000-file skewed worktree (objects above the device's size limit go to host threads within the same batch), the
+    1,000-file one and the one with odd names; and with the device path off the files are the same again."""
+    force = {"VIT_DEVICE_DEFLATE": "1", "VIT_DEVICE_DEFLATE_MIN": "1"}
+    for name in ("nested_names", "c1_1000x4096", [k for k in golden_trees if golden_trees[k].get("spec") == "skew"][0]):
+        wt = fresh_copy(worktrees[name], tmp_path / ("dd_" + name))
+        p = vit(wt, "write-tree", "--stats", env=force)
+        assert p.stdout.decode().strip() == golden_trees[name]["root"]
+        stats = p.stderr.decode()
+        done = int(stats.split(" s (")[1].split(" objects)")[0])
+        assert done > 0, stats                                         # the device really made streams
+        ref_dir = tmp_path / ("oracle_" + name)
+        oracle.write_tree(worktrees[name], str(ref_dir))
+        n = 0
+        for d in os.listdir(ref_dir):
+            for f in os.listdir(ref_dir / d):
+                assert open(os.path.join(wt, ".git", "objects", d, f), "rb").read() == open(ref_dir / d / f, "rb").read(), d + f
+                n += 1
+        assert n >= len(set(golden_trees[name]["blob_ids"]))
+        host = fresh_copy(worktrees[name], tmp_path / ("hd_" + name))
+        q = vit(host, "write-tree", "--stats", "--host-deflate")
+        assert " s (0 objects)" in q.stderr.decode()
+        assert stored_objects(host).keys() == stored_objects(wt).keys()
+
+
 def test_git_reads_what_write_tree_stored(golden_trees, worktrees, tmp_path):
     if not shutil.which("git"):
         pytest.skip("no git here")

@@ -558,12 +558,17 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
     //   ids of batch k on the GPU (this thread; packing on the hasher's threads)
     //   deflate + store of batches k-1, k (pool, low priority: by far the most work)
     // A batch's contents live in one of three slots until its objects are stored.
-    const bool on_device = device_deflate_ && store_ && (deflate_level_ == -1 || deflate_level_ == 6) && ensureDeflateHasher();
     // With the device deflating there is a fourth stage (streams of batch k on the GPU, through a hasher and a
-    // thread of its own, while this thread reads and hashes batch k+1), hence a fourth slot; and the deflate kernel
-    // wants tens of thousands of objects per launch: fewer, larger batches.
-    const size_t ns = on_device ? 4 : 3;
-    uint64_t batch_bytes = on_device ? std::max<uint64_t>(batch_bytes_, 512ull << 20) : batch_bytes_;
+    // thread of its own, while this thread reads and hashes batch k+1), hence a fourth slot.  Whether a batch goes
+    // that way is decided batch by batch: the kernel needs tens of thousands of small objects to fill the chip (a
+    // launch lasts as long as its longest object on one lane, about 10 us per byte), fewer are done sooner by the
+    // host threads.
+    const bool may_device = device_deflate_ && store_ && (deflate_level_ == -1 || deflate_level_ == 6);
+    uint64_t device_min_objects = 16384, device_max_bytes = 16384;
+    if (const char* e = std::getenv("VIT_DEVICE_DEFLATE_MIN")) device_min_objects = std::strtoull(e, nullptr, 10);
+    if (const char* e = std::getenv("VIT_DEVICE_DEFLATE_MAX")) device_max_bytes = std::strtoull(e, nullptr, 10);
+    const size_t ns = may_device ? 4 : 3;
+    uint64_t batch_bytes = batch_bytes_;
     if (const char* e = std::getenv("VIT_BATCH_MB")) batch_bytes = std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)) << 20;
     struct Slot {
         std::vector<std::string> contents;
@@ -579,7 +584,6 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
         ~FreePinned() { for (int k = 0; k < 4; ++k) if (s[k].zbuf) vit_arena_free(h, s[k].zbuf); }
     } free_pinned{hasher_, slot};
     std::unique_ptr<SerialWorker> deflater;               // after the slots: joined before they go
-    if (on_device) deflater.reset(new SerialWorker());
     std::vector<std::pair<size_t, size_t>> batches;
     for (size_t pos = 0; pos < files.size();) {
         size_t end = pos;
@@ -646,7 +650,14 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
             stats_.bytes += s.contents[i].size();
         }
         stats_.blobs += s.contents.size();
+        bool on_device = false;
+        if (may_device) {
+            uint64_t small = 0;
+            for (const std::string& c : s.contents) small += c.size() + 32 <= device_max_bytes;
+            on_device = small >= device_min_objects && ensureDeflateHasher();
+        }
         if (on_device) {
+            if (!deflater) deflater.reset(new SerialWorker());
             Slot* sp = &s;
             s.deflate = deflater->post([this, sp, k, &mark] {
                 Slot& s = *sp;

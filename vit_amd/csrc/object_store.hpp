@@ -89,9 +89,10 @@ public:
     // reference's in their bytes but hold the same object (they inflate to the same "<type> <len>\0" + content, so the
     // reference's readObject and git read them); level 1 deflates about three times faster, level 0 stores.
     void setDeflateLevel(int level) { deflate_level_ = level < -1 ? -1 : (level > 9 ? 9 : level); }
-    // Where the small objects of a write-tree are deflated.  true: on the GPU, by the kernel that writes the zlib
-    // library's own bytes (vit_deflate_objects; objects above its size limit still go to host threads), so that the
-    // host threads are left with creating files.  Only at the default level: any other level is the host's.
+    // Where the small objects of a write-tree are deflated.  true (default): batches that hold at least 16384 objects
+    // of up to 16 KiB are deflated on the GPU, by the kernel that writes the zlib library's own bytes
+    // (vit_deflate_objects; their longer objects, and smaller batches, still go to host threads), so that the host
+    // threads are left with creating files.  Only at the default level: any other level is the host's.
     void setDeviceDeflate(bool on) { device_deflate_ = on; }
     void setIoThreads(int n) { io_threads_ = n < 1 ? 1 : n; }
     void setBatchBytes(uint64_t b) { batch_bytes_ = b < 1 ? 1 : b; }
@@ -122,7 +123,7 @@ private:
     bool skip_existing_ = true;
     bool git_rules_ = false;
     int deflate_level_ = -1;
-    bool device_deflate_ = false;
+    bool device_deflate_ = true;
     int io_threads_ = 8;
     // Blobs per hashing batch, by bytes.  128 MiB: a dozen or more batches on a worktree of gigabytes, so that
     // reading, hashing and storing overlap, and three batches of contents in memory at most.
