@@ -13,10 +13,6 @@ check = int(sys.argv[3]) if len(sys.argv) > 3 else min(n, 5000)
 h = vit_amd.Hasher((0,))
 if os.environ.get("VIT_DEFLATE_LANES"):
     h.set_option("deflate_lanes", int(os.environ["VIT_DEFLATE_LANES"]))
-if os.environ.get("VIT_DEFLATE_OCC"):
-    occ = int(os.environ["VIT_DEFLATE_OCC"])
-    h.set_option("deflate_occupancy", occ)
-    h.set_option("deflate_lanes", 65536 * occ)
 rng = np.random.default_rng(8)
 lens = np.full(n, L, dtype=np.uint64) if L else np.minimum(np.exp(rng.normal(np.log(3000.0), 1.3, n)), 60000).astype(np.uint64)
 b = h.synth_arena("blob", 0x5EED00AA, 0, n, 0, lens=lens)

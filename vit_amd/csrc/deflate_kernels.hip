@@ -7,11 +7,12 @@
 //
 // One lane runs one object from start to finish: deflate is a serial scan with a hash table, as
 // SHA-1 is a serial chain.  The tables a lane needs (zlib's head and prev arrays, the symbol
-// buffers of a block: 176 KiB) live in a workspace slot per lane in device memory; the Huffman
-// construction's small arrays are private to the lane.  A wave takes 64 objects at a time and
-// moves on to its next 64 when the longest of them is done.  The work is bound by scattered
-// two-byte accesses to those tables (three per input byte), i.e. by how many lanes the memory
-// system keeps in flight, not by arithmetic.
+// buffers of a block, the Huffman construction's arrays: 181 KiB) live in device memory, one
+// workspace per wave with the 64 lanes' entries interleaved.  A wave takes 64 objects at a time
+// and moves on to its next 64 when the longest of them is done.  The work is bound by scattered
+// two-byte accesses to those tables (the scan, and the Huffman heap of every block), i.e. by the
+// memory system's transaction rate, not by arithmetic: about 10 us per input byte and lane,
+// 1.7 M objects of 4 KiB per second over the chip.
 #include "kernels.h"
 #include "zdeflate.h"
 
@@ -27,8 +28,9 @@ struct ArenaBytes {
 
 }  // namespace
 
-template <int OCC>
-__global__ __launch_bounds__(64, OCC) void deflate_kernel(DeflateBatch b)
+// (The register allocator takes every register it may for this much inlined code: one wave per SIMD, 65536 lanes
+// on the chip, whatever occupancy is asked for; more lanes would only wait on the same memory system.)
+__global__ __launch_bounds__(64) void deflate_kernel(DeflateBatch b)
 {
     const uint32_t lane = threadIdx.x;
     // One workspace per wave; in every table of it the 64 lanes' entries are interleaved (entry e of
@@ -94,19 +96,14 @@ void deflate_make_tables(void* host_dst) { zd::make_tables(*static_cast<zd::Tabl
 uint32_t deflate_bound(uint32_t framed_len) { return zd::bound(framed_len); }
 uint32_t deflate_max_input() { return zd::kMaxInput; }
 
-hipError_t launch_deflate(const DeflateBatch& b, uint32_t lanes, int waves_per_simd, hipStream_t stream)
+hipError_t launch_deflate(const DeflateBatch& b, uint32_t lanes, hipStream_t stream)
 {
     if (b.n == 0) return hipSuccess;
     if (!b.workspace || !b.tables_raw || lanes < 64) return hipErrorInvalidValue;
     uint32_t waves = lanes / 64u;
     const uint64_t need = ((uint64_t)b.n + 63u) / 64u;
     if (waves > need) waves = (uint32_t)need;
-    switch (waves_per_simd) {
-    case 1:  hipLaunchKernelGGL(deflate_kernel<1>, dim3(waves), dim3(64), 0, stream, b); break;
-    case 2:  hipLaunchKernelGGL(deflate_kernel<2>, dim3(waves), dim3(64), 0, stream, b); break;
-    case 8:  hipLaunchKernelGGL(deflate_kernel<8>, dim3(waves), dim3(64), 0, stream, b); break;
-    default: hipLaunchKernelGGL(deflate_kernel<4>, dim3(waves), dim3(64), 0, stream, b); break;
-    }
+    hipLaunchKernelGGL(deflate_kernel, dim3(waves), dim3(64), 0, stream, b);
     return hipGetLastError();
 }
 

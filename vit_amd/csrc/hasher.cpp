@@ -134,8 +134,7 @@ struct vit_hasher {
     uint64_t calibrate_ns = 0;
     uint64_t fail_at_chunk = 0;                           // fault injection for tests: 0 = off
     uint64_t deflate_max_bytes = 16384;                   // vit_deflate_objects: longer objects (framed) are left to the host
-    int deflate_occupancy = 4;                            // waves per SIMD the deflate kernel is compiled for (1, 2, 4, 8)
-    uint32_t deflate_lanes = 65536;                       // objects the deflate kernel keeps in flight (176 KiB of device memory each)
+    uint32_t deflate_lanes = 65536;                       // objects the deflate kernel keeps in flight (181 KiB of device memory each)
     std::atomic<uint64_t> objects_gpu{0}, objects_host{0}, bytes_host{0}, blocks_gpu{0}, bytes_h2d{0}, launches{0};
     uint64_t last_host_threshold = 0, last_host_objects = 0;
     uint64_t last_kernel_ns = 0, last_pack_ns = 0, last_total_ns = 0;
@@ -872,7 +871,6 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     else if (k == "host_bias_percent") h->host_bias = value ? double(value) / 100.0 : 1.0;
     else if (k == "debug_fail_at_chunk") h->fail_at_chunk = value;
     else if (k == "deflate_max_bytes") h->deflate_max_bytes = std::min<uint64_t>(value, vit::deflate_max_input());
-    else if (k == "deflate_occupancy") h->deflate_occupancy = int(value);
     else if (k == "deflate_lanes") h->deflate_lanes = uint32_t(std::min<uint64_t>(std::max<uint64_t>(value, 64), 1u << 20) / 64 * 64);
     else if (k == "sched_waves") h->sched_waves = uint32_t(value > 8 ? 8 : value);
     else if (k == "sched_share_below") h->sched_share_below = uint32_t(value > 0xFFFFFFFEull ? 0xFFFFFFFEu : value);
@@ -1354,7 +1352,7 @@ int vit_deflate_arena_device(vit_hasher* h, int dev, const void* d_arena, uint64
     b.offsets = d_offsets; b.nblocks = d_nblocks; b.n = uint32_t(n); b.order = d_order;
     b.out = d_out; b.out_off = d_out_offsets; b.out_len = d_out_lens;
     b.workspace = q->z_workspace; b.tables_raw = q->z_tables; b.status = q->d_status;
-    HIP_TRY(h, vit::launch_deflate(b, q->z_lanes, h->deflate_occupancy, stream ? static_cast<hipStream_t>(stream) : q->stream[0]));
+    HIP_TRY(h, vit::launch_deflate(b, q->z_lanes, stream ? static_cast<hipStream_t>(stream) : q->stream[0]));
     return VIT_OK;
 }
 
@@ -1452,7 +1450,7 @@ int vit_deflate_objects(vit_hasher* h, const char* type, const uint8_t* const* d
         b.order = binned ? s.d_order : nullptr;
         b.out = q.z_out; b.out_off = d_zoff; b.out_len = d_zlen;
         b.workspace = q.z_workspace; b.tables_raw = q.z_tables; b.status = q.d_status;
-        HIP_TRY(h, vit::launch_deflate(b, q.z_lanes, h->deflate_occupancy, stream));
+        HIP_TRY(h, vit::launch_deflate(b, q.z_lanes, stream));
         HIP_TRY(h, hipMemcpyAsync(out + out_lo, q.z_out, out_hi - out_lo, hipMemcpyDeviceToHost, stream));
         HIP_TRY(h, hipMemcpyAsync(h_zlen, d_zlen, cnt * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(h, hipStreamSynchronize(stream));

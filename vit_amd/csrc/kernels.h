@@ -134,7 +134,7 @@ uint64_t deflate_tables_bytes();
 void deflate_make_tables(void* host_dst);
 uint32_t deflate_bound(uint32_t framed_len);
 uint32_t deflate_max_input();
-hipError_t launch_deflate(const DeflateBatch& b, uint32_t lanes, int waves_per_simd, hipStream_t stream);
+hipError_t launch_deflate(const DeflateBatch& b, uint32_t lanes, hipStream_t stream);
 
 // Compute-only ceiling: every lane runs `blocks_per_lane` SHA-1 compressions on
 // register-resident data (no loads in the loop).  out: one dword per lane.

@@ -139,26 +139,6 @@ bool deflateFramed(int level, const std::string& type, const std::string& conten
     return deflater.run(level, type, content, out);
 }
 
-// Write atomically: a reader (or a crash) never sees a half-written object.
-bool writeFileAtomic(const std::string& path, const char* data, size_t size);
-bool writeFileAtomic(const std::string& path, const std::string& bytes) { return writeFileAtomic(path, bytes.data(), bytes.size()); }
-bool writeFileAtomic(const std::string& path, const char* data, size_t size)
-{
-    static std::atomic<uint64_t> serial{0};
-    const std::string tmp = path + ".tmp" + std::to_string(uint64_t(getpid())) + "_" + std::to_string(serial++);
-    const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
-    if (fd < 0) return false;
-    size_t put = 0;
-    while (put < size) {
-        const ssize_t w = ::write(fd, data + put, size - put);
-        if (w < 0 && errno == EINTR) continue;
-        if (w <= 0) { ::close(fd); ::unlink(tmp.c_str()); return false; }
-        put += size_t(w);
-    }
-    if (::close(fd) != 0 || ::rename(tmp.c_str(), path.c_str()) != 0) { ::unlink(tmp.c_str()); return false; }
-    return true;
-}
-
 // Whole file into a string.  size_hint is the size seen during the walk: the
 // buffer is one byte larger, so a file that still has that size is read, and
 // its end detected, by a single read() (open + read + close per file; a million
@@ -449,14 +429,56 @@ bool ObjectStore::hashObjects(const std::string& type, const std::vector<const s
     return true;
 }
 
-// A loose object that is already in place: a regular file with something in it.
-// (An empty or truncated-to-nothing file, as a crashed non-atomic writer such as
-// the reference's leaves behind, is written again.)
-static bool alreadyStored(const std::string& path)
+// A loose object that is already in place is a regular file with something in it (an empty or
+// truncated-to-nothing file, as a crashed non-atomic writer such as the reference's leaves behind, is written
+// again); objects are written atomically (temporary name, then rename: a reader or a crash never sees half an
+// object).  Both go through a directory handle: a million objects go into 256 directories, and naming each of them by
+// its full path has the kernel walk .../.git/objects/xx afresh for every stat, create and rename.  Every worker
+// thread keeps its own handles (the pool's threads have private descriptor tables).
+namespace {
+struct FanoutDirs {
+    const void* owner = nullptr;                          // the store the handles belong to
+    uint64_t generation = 0;
+    int fd[256];
+    FanoutDirs() { for (int& f : fd) f = -1; }
+    ~FanoutDirs() { drop(); }
+    void drop() { for (int& f : fd) if (f >= 0) { ::close(f); f = -1; } }
+    int get(const void* store, uint64_t gen, const std::string& objects_dir, uint8_t byte)
+    {
+        if (owner != store || generation != gen) { drop(); owner = store; generation = gen; }
+        if (fd[byte] < 0) {
+            const std::string dir = objects_dir + '/' + toHex(&byte, 1);
+            fd[byte] = ::open(dir.c_str(), O_RDONLY | O_DIRECTORY | O_CLOEXEC);
+        }
+        return fd[byte];
+    }
+};
+
+bool storedAt(int dirfd, const char* name)
 {
     struct stat st;
-    return ::stat(path.c_str(), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0;
+    return ::fstatat(dirfd, name, &st, 0) == 0 && S_ISREG(st.st_mode) && st.st_size > 0;
 }
+
+bool writeFileAtomicAt(int dirfd, const char* name, const char* data, size_t size)
+{
+    static std::atomic<uint64_t> serial{0};
+    char tmp[96];
+    std::snprintf(tmp, sizeof tmp, "%s.tmp%llu_%llu", name, static_cast<unsigned long long>(getpid()),
+                  static_cast<unsigned long long>(serial++));
+    const int fd = ::openat(dirfd, tmp, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
+    if (fd < 0) return false;
+    size_t put = 0;
+    while (put < size) {
+        const ssize_t w = ::write(fd, data + put, size - put);
+        if (w < 0 && errno == EINTR) continue;
+        if (w <= 0) { ::close(fd); ::unlinkat(dirfd, tmp, 0); return false; }
+        put += size_t(w);
+    }
+    if (::close(fd) != 0 || ::renameat(dirfd, tmp, dirfd, name) != 0) { ::unlinkat(dirfd, tmp, 0); return false; }
+    return true;
+}
+}  // namespace
 
 // Queue deflate + write of objects whose ids are known; `contents` and `raw`
 // must stay alive until the ticket has been waited for.  Low priority: file
@@ -477,18 +499,25 @@ WorkPool::Ticket ObjectStore::storeAsync(const std::string& type, const std::vec
     const std::string* c = contents.data();
     const uint8_t* r = raw.data();
     const int level = deflate_level_;
-    return pool().submit(WorkPool::LOW, slices, [this, type, c, r, n, slices, level, dz, &outcome](size_t s) {
+    const uint64_t dirs_generation = store_calls_;        // handles are good for one top-level call: between calls the directories may have been replaced
+    return pool().submit(WorkPool::LOW, slices, [this, type, c, r, n, slices, level, dz, dirs_generation, &outcome](size_t s) {
         for (size_t i = n * s / slices; i < n * (s + 1) / slices; ++i) {
             try {
-                const std::string path = objectPath(toHex(r + i * 20, 20));
-                if (skip_existing_ && alreadyStored(path)) { ++outcome.skipped; continue; }
+                static thread_local FanoutDirs dirs;
+                const int dirfd = dirs.get(this, dirs_generation, objects_dir_, r[i * 20]);
+                if (dirfd < 0) { outcome.failed = 2; continue; }
+                char name[40];
+                static const char hex[] = "0123456789abcdef";
+                for (int b = 1; b < 20; ++b) { name[2 * b - 2] = hex[r[i * 20 + b] >> 4]; name[2 * b - 1] = hex[r[i * 20 + b] & 15]; }
+                name[38] = 0;
+                if (skip_existing_ && storedAt(dirfd, name)) { ++outcome.skipped; continue; }
                 if (dz.buf && dz.len[i]) {                 // the device has made this object's stream already
-                    if (!writeFileAtomic(path, reinterpret_cast<const char*>(dz.buf + dz.off[i]), dz.len[i])) outcome.failed = 2;
+                    if (!writeFileAtomicAt(dirfd, name, reinterpret_cast<const char*>(dz.buf + dz.off[i]), dz.len[i])) outcome.failed = 2;
                     continue;
                 }
                 std::string z;
                 if (!deflateFramed(level, type, c[i], z)) { outcome.failed = 1; continue; }
-                if (!writeFileAtomic(path, z)) outcome.failed = 2;
+                if (!writeFileAtomicAt(dirfd, name, z.data(), z.size())) outcome.failed = 2;
             } catch (const std::exception&) { outcome.failed = 2; }      // out of memory in deflate or the path strings
         }
     });
@@ -507,6 +536,7 @@ std::vector<std::string> ObjectStore::writeObjects(const std::string& type, cons
     const size_t n = contents.size();
     std::vector<std::string> ids;
     if (n == 0) return ids;
+    if (!in_write_tree_) ++store_calls_;
     std::vector<const std::string*> view(n);
     for (size_t i = 0; i < n; ++i) view[i] = &contents[i];
 
@@ -541,6 +571,8 @@ std::string ObjectStore::writeObject(const std::string& type, const std::string&
 std::string ObjectStore::writeTree(const std::string& directoryPath)
 {
     stats_ = StoreStats();
+    ++store_calls_;
+    struct InTree { bool& f; InTree(bool& x) : f(x) { f = true; } ~InTree() { f = false; } } in_tree(in_write_tree_);
     const auto t_all = clk::now();
     if (!ensureHasher()) return {};
     stats_.init_s = since(t_all);                        // the HIP runtime starting up under the first hasher, mostly
@@ -602,6 +634,7 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
         if (!s.store) return true;
         workers.wait(s.store);
         s.store.reset();
+        mark("a slot's objects are stored", size_t(&s - slot));
         return storeFinished(s.outcome);
     };
     auto start_read = [&](size_t k) {

@@ -129,6 +129,8 @@ private:
     // reading, hashing and storing overlap, and three batches of contents in memory at most.
     uint64_t batch_bytes_ = 128ull << 20;
     StoreStats stats_;
+    std::atomic<uint64_t> store_calls_{0};
+    bool in_write_tree_ = false;
 };
 
 // The store behind the free functions below: ".git/objects" relative to the
