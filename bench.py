@@ -19,7 +19,8 @@ wait on a CPU barrier, their GPUs idle):
                            host path, strong scaling (the slice is the same whatever N)
       mixed_slice_weak     (N > 1) the same with N times the objects: weak scaling of that path
   cpu_baseline             (N = 1) the reference's hashing loop and its whole write-tree, restated on
-                           the host's cores, on bounded samples
+                           the host's cores, on bounded samples; `vit write-tree` beside it, also on the
+                           whole 1,000,000-file worktree (write_tree.c2_headline)
 
 Prints ONE JSON line on rank 0.
 """
@@ -275,7 +276,60 @@ def cpu_write_tree(O):
             res[name] = rec
         finally:
             shutil.rmtree(top, ignore_errors=True)
+    res["c2_headline"] = headline_write_tree(O, vit)
     return res
+
+
+# Tree id of the 1,000,000-file worktree of make_c2: what the CPU restatement, the reference's own code and git
+# each gave for it (profiles/r02_write_tree_c2.json, profiles/r01_wt_c2.txt).
+C2_ROOT = "2b90a3b6ca988135837e12254363cb7054f21a0c"
+
+
+def headline_write_tree(O, vit, files=1_000_000, cpu_files=50_000):
+    """BASELINE configs[1] as a worktree: `vit write-tree` on all 1,000,000 files x 4 KiB (ids, zlib streams, loose
+    objects); the CPU restatement on the first 50,000 of them (the whole takes it about 50 s)."""
+    import shutil
+    import subprocess
+    import tempfile
+    rec = {"workload": "BASELINE configs[1] as files: %d x 4 KiB, 1,000 per directory" % files, "files": files,
+           "bytes": files * 4096}
+    top = tempfile.mkdtemp(prefix="vit_bench_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        # the worktrees are made by a child process (it forks workers; this process holds the GPU)
+        make = lambda where, count: subprocess.check_call(
+            [sys.executable, os.path.join(HERE, "tools", "bench_write_tree.py"), "c2", "--make-only", "--dir", where,
+             "--files", str(count)], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        make(os.path.join(top, "cpu"), cpu_files)
+        small = os.path.join(top, "cpu", "wt")
+        t0 = time.perf_counter()
+        _, nb, nt = O.write_tree(small, os.path.join(top, "cpu_objects"))
+        cpu_s = time.perf_counter() - t0
+        rec.update({"cpu_sample_files": cpu_files, "cpu_sample_s": round(cpu_s, 3),
+                    "cpu_objects_per_s": round((nb + nt) / cpu_s, 1)})
+        shutil.rmtree(os.path.join(top, "cpu"), ignore_errors=True)
+        shutil.rmtree(os.path.join(top, "cpu_objects"), ignore_errors=True)
+        if os.path.exists(vit):
+            make(os.path.join(top, "gpu"), files)
+            wt = os.path.join(top, "gpu", "wt")
+            env = dict(os.environ)
+            env.setdefault("VIT_DEVICES", "0")
+            subprocess.check_call([vit, "init"], cwd=wt, stdout=subprocess.DEVNULL, env=env)
+            t0 = time.perf_counter()
+            p = subprocess.run([vit, "write-tree", "--stats"], cwd=wt, capture_output=True, env=env, timeout=300)
+            wall = time.perf_counter() - t0
+            stats = p.stderr.decode().strip().splitlines()[-1] if p.stderr else ""
+            inner = float(stats.split(" total ")[1].split()[0]) if " total " in stats else None
+            objects = files + (files + 999) // 1000 + 1
+            rec.update({"gpu_s": inner, "gpu_wall_s_with_process_start": round(wall, 3),
+                        "gpu_objects_per_s": round(objects / inner, 1) if inner else None,
+                        "gpu_root": p.stdout.decode().strip(),
+                        "gpu_root_matches": (p.stdout.decode().strip() == C2_ROOT) if files == 1_000_000 else None,
+                        "gpu_stats": stats})
+    except Exception as e:                                       # a side leg must not lose the measured line
+        rec["error"] = repr(e)
+    finally:
+        shutil.rmtree(top, ignore_errors=True)
+    return rec
 
 
 def main():

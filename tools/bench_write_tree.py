@@ -110,7 +110,15 @@ def main():
     ap.add_argument("--skip-reference", action="store_true")
     ap.add_argument("--levels", type=int, nargs="*", default=[],
                     help="also run `vit write-tree --deflate-level=N` for these zlib levels (same ids, other stored bytes)")
+    ap.add_argument("--make-only", action="store_true", help="build the worktree under --dir/wt and stop (bench.py's generator)")
     a = ap.parse_args()
+    if a.make_only:
+        wt = os.path.join(a.dir, "wt")
+        os.makedirs(wt, exist_ok=True)
+        n, total = (make_c1(wt) if a.config == "c1" else make_c2(wt, a.files or 1_000_000) if a.config == "c2"
+                    else make_c3(wt, a.files or 80000))
+        print(json.dumps({"files": n, "bytes": total}))
+        return
     base = a.dir or tempfile.mkdtemp(prefix="vitwt_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     wt = os.path.join(base, "wt")
     os.makedirs(wt, exist_ok=True)
