@@ -16,12 +16,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VIT = os.path.join(ROOT, "vit_amd", "bin", "vit")
 
 
-def vit(cwd, *args, env=None, check=True):
+def vit(cwd, *args, env=None, check=True, nofile=None):
     e = dict(os.environ)
     e.setdefault("VIT_DEVICES", "0")
     if env:
         e.update(env)
-    p = subprocess.run([VIT] + list(args), cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=240)
+    limit = None
+    if nofile is not None:
+        import resource
+        limit = lambda: resource.setrlimit(resource.RLIMIT_NOFILE, (nofile, nofile))
+    p = subprocess.run([VIT] + list(args), cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=240,
+                       preexec_fn=limit)
     if check:
         assert p.returncode == 0, p.stderr.decode()
     return p
@@ -102,6 +107,17 @@ def test_device_deflate_stores_the_files_the_library_would(oracle, golden_trees,
         q = vit(host, "write-tree", "--stats", "--host-deflate")
         assert " s (0 objects)" in q.stderr.decode()
         assert stored_objects(host).keys() == stored_objects(wt).keys()
+
+
+def test_write_tree_with_fewer_descriptors_than_fanout_directories(golden_trees, worktrees, tmp_path):
+    """The storing threads keep a handle per objects/xx directory; where the descriptor limit is below the 256 of
+    them (plus what the runtime holds), they give handles back and carry on: same id, every object stored."""
+    name = [k for k in golden_trees if golden_trees[k].get("spec") == "skew"][0]
+    wt = fresh_copy(worktrees[name], tmp_path / "fewfds")
+    p = vit(wt, "write-tree", nofile=192)
+    assert p.stdout.decode().strip() == golden_trees[name]["root"], p.stderr.decode()
+    objs = stored_objects(wt)
+    assert set(golden_trees[name]["blob_ids"]) <= set(objs) and set(golden_trees[name]["tree_ids"]) <= set(objs)
 
 
 def test_git_reads_what_write_tree_stored(golden_trees, worktrees, tmp_path):

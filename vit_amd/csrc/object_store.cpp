@@ -43,10 +43,11 @@ double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now
 // than four do (measured on tmpfs: 1.0 us per file on 16 threads with the shared
 // table, 0.41 us on 8 with private ones).  A worker only ever uses descriptors it
 // opened itself, so nothing is lost by not seeing the other threads'.
+thread_local bool tl_private_fd_table = false;
 void privateFdTable()
 {
 #ifdef __linux__
-    (void)::unshare(CLONE_FILES);
+    tl_private_fd_table = ::unshare(CLONE_FILES) == 0;
 #endif
 }
 
@@ -139,6 +140,38 @@ bool deflateFramed(int level, const std::string& type, const std::string& conten
     return deflater.run(level, type, content, out);
 }
 
+// Handles of the objects/xx directories, one set per thread (see storeAsync).
+struct FanoutDirs {
+    const void* owner = nullptr;                          // the store the handles belong to
+    uint64_t generation = 0;
+    int fd[256];
+    FanoutDirs() { for (int& f : fd) f = -1; }
+    ~FanoutDirs() { drop(); }
+    void drop() { for (int& f : fd) if (f >= 0) { ::close(f); f = -1; } }
+    int get(const void* store, uint64_t gen, const std::string& objects_dir, uint8_t byte)
+    {
+        if (!tl_private_fd_table) return -1;              // handles are kept only in a table of the thread's own: in a shared one
+                                                          // every thread's 256 would count against the one limit
+        if (owner != store || generation != gen) { drop(); owner = store; generation = gen; }
+        if (fd[byte] < 0) {
+            const std::string dir = objects_dir + '/' + toHex(&byte, 1);
+            fd[byte] = ::open(dir.c_str(), O_RDONLY | O_DIRECTORY | O_CLOEXEC);
+            if (fd[byte] < 0 && (errno == EMFILE || errno == ENFILE)) {      // a descriptor limit below the 256 directories: give the
+                drop();                                                        // handles back and start over
+                fd[byte] = ::open(dir.c_str(), O_RDONLY | O_DIRECTORY | O_CLOEXEC);
+            }
+        }
+        return fd[byte];
+    }
+};
+
+// The calling thread's handles.
+FanoutDirs& threadDirs()
+{
+    static thread_local FanoutDirs dirs;
+    return dirs;
+}
+
 // Whole file into a string.  size_hint is the size seen during the walk: the
 // buffer is one byte larger, so a file that still has that size is read, and
 // its end detected, by a single read() (open + read + close per file; a million
@@ -146,7 +179,11 @@ bool deflateFramed(int level, const std::string& type, const std::string& conten
 std::string slurp(const std::string& path, uint64_t size_hint)
 {
     // reference src/commit.cpp:151-152: an unreadable file yields empty content.
-    const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0 && (errno == EMFILE || errno == ENFILE)) {  // out of descriptors is not "unreadable": this thread gives its
+        threadDirs().drop();                               // directory handles back and tries again
+        fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    }
     if (fd < 0) return {};
     std::string s(size_t(size_hint) + 1, '\0');
     size_t got = 0;
@@ -436,23 +473,14 @@ bool ObjectStore::hashObjects(const std::string& type, const std::vector<const s
 // its full path has the kernel walk .../.git/objects/xx afresh for every stat, create and rename.  Every worker
 // thread keeps its own handles (the pool's threads have private descriptor tables).
 namespace {
-struct FanoutDirs {
-    const void* owner = nullptr;                          // the store the handles belong to
-    uint64_t generation = 0;
-    int fd[256];
-    FanoutDirs() { for (int& f : fd) f = -1; }
-    ~FanoutDirs() { drop(); }
-    void drop() { for (int& f : fd) if (f >= 0) { ::close(f); f = -1; } }
-    int get(const void* store, uint64_t gen, const std::string& objects_dir, uint8_t byte)
-    {
-        if (owner != store || generation != gen) { drop(); owner = store; generation = gen; }
-        if (fd[byte] < 0) {
-            const std::string dir = objects_dir + '/' + toHex(&byte, 1);
-            fd[byte] = ::open(dir.c_str(), O_RDONLY | O_DIRECTORY | O_CLOEXEC);
-        }
-        return fd[byte];
-    }
-};
+
+// One number per top-level storing call, over every store of the process: a thread's cached handles are never taken
+// for those of another call, even of a store that has since been destroyed and another created at its address.
+uint64_t nextStoreCall()
+{
+    static std::atomic<uint64_t> calls{0};
+    return ++calls;
+}
 
 bool storedAt(int dirfd, const char* name)
 {
@@ -460,23 +488,23 @@ bool storedAt(int dirfd, const char* name)
     return ::fstatat(dirfd, name, &st, 0) == 0 && S_ISREG(st.st_mode) && st.st_size > 0;
 }
 
-bool writeFileAtomicAt(int dirfd, const char* name, const char* data, size_t size)
+// 0, or the errno of the step that failed.
+int writeFileAtomicAt(int dirfd, const char* name, const char* data, size_t size)
 {
     static std::atomic<uint64_t> serial{0};
-    char tmp[96];
-    std::snprintf(tmp, sizeof tmp, "%s.tmp%llu_%llu", name, static_cast<unsigned long long>(getpid()),
-                  static_cast<unsigned long long>(serial++));
+    const std::string tmp_name = std::string(name) + ".tmp" + std::to_string(getpid()) + '_' + std::to_string(serial++);
+    const char* const tmp = tmp_name.c_str();
     const int fd = ::openat(dirfd, tmp, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0644);
-    if (fd < 0) return false;
+    if (fd < 0) return errno ? errno : EIO;
     size_t put = 0;
     while (put < size) {
         const ssize_t w = ::write(fd, data + put, size - put);
         if (w < 0 && errno == EINTR) continue;
-        if (w <= 0) { ::close(fd); ::unlinkat(dirfd, tmp, 0); return false; }
+        if (w <= 0) { const int e = w < 0 && errno ? errno : EIO; ::close(fd); ::unlinkat(dirfd, tmp, 0); return e; }
         put += size_t(w);
     }
-    if (::close(fd) != 0 || ::renameat(dirfd, tmp, dirfd, name) != 0) { ::unlinkat(dirfd, tmp, 0); return false; }
-    return true;
+    if (::close(fd) != 0 || ::renameat(dirfd, tmp, dirfd, name) != 0) { const int e = errno ? errno : EIO; ::unlinkat(dirfd, tmp, 0); return e; }
+    return 0;
 }
 }  // namespace
 
@@ -503,21 +531,36 @@ WorkPool::Ticket ObjectStore::storeAsync(const std::string& type, const std::vec
     return pool().submit(WorkPool::LOW, slices, [this, type, c, r, n, slices, level, dz, dirs_generation, &outcome](size_t s) {
         for (size_t i = n * s / slices; i < n * (s + 1) / slices; ++i) {
             try {
-                static thread_local FanoutDirs dirs;
-                const int dirfd = dirs.get(this, dirs_generation, objects_dir_, r[i * 20]);
-                if (dirfd < 0) { outcome.failed = 2; continue; }
-                char name[40];
+                FanoutDirs& dirs = threadDirs();
+                int dirfd = dirs.get(this, dirs_generation, objects_dir_, r[i * 20]);
+                char leaf[40];
                 static const char hex[] = "0123456789abcdef";
-                for (int b = 1; b < 20; ++b) { name[2 * b - 2] = hex[r[i * 20 + b] >> 4]; name[2 * b - 1] = hex[r[i * 20 + b] & 15]; }
-                name[38] = 0;
+                for (int b = 1; b < 20; ++b) { leaf[2 * b - 2] = hex[r[i * 20 + b] >> 4]; leaf[2 * b - 1] = hex[r[i * 20 + b] & 15]; }
+                leaf[38] = 0;
+                const char* name = leaf;
+                std::string full;
+                if (dirfd < 0) {                           // no handle to be had: name the object by its whole path instead
+                    full = objects_dir_ + '/' + toHex(&r[i * 20], 1) + '/' + leaf;
+                    name = full.c_str();
+                    dirfd = AT_FDCWD;
+                }
                 if (skip_existing_ && storedAt(dirfd, name)) { ++outcome.skipped; continue; }
+                auto put = [&](const char* data, size_t size) {
+                    int err = writeFileAtomicAt(dirfd, name, data, size);
+                    if (err == EMFILE || err == ENFILE) {  // the handles themselves have used the descriptors up: give them back
+                        dirs.drop();
+                        if (full.empty()) full = objects_dir_ + '/' + toHex(&r[i * 20], 1) + '/' + leaf;
+                        err = writeFileAtomicAt(AT_FDCWD, full.c_str(), data, size);
+                    }
+                    if (err) outcome.failed = 2;
+                };
                 if (dz.buf && dz.len[i]) {                 // the device has made this object's stream already
-                    if (!writeFileAtomicAt(dirfd, name, reinterpret_cast<const char*>(dz.buf + dz.off[i]), dz.len[i])) outcome.failed = 2;
+                    put(reinterpret_cast<const char*>(dz.buf + dz.off[i]), dz.len[i]);
                     continue;
                 }
                 std::string z;
                 if (!deflateFramed(level, type, c[i], z)) { outcome.failed = 1; continue; }
-                if (!writeFileAtomicAt(dirfd, name, z.data(), z.size())) outcome.failed = 2;
+                put(z.data(), z.size());
             } catch (const std::exception&) { outcome.failed = 2; }      // out of memory in deflate or the path strings
         }
     });
@@ -536,7 +579,7 @@ std::vector<std::string> ObjectStore::writeObjects(const std::string& type, cons
     const size_t n = contents.size();
     std::vector<std::string> ids;
     if (n == 0) return ids;
-    if (!in_write_tree_) ++store_calls_;
+    if (!in_write_tree_) store_calls_ = nextStoreCall();
     std::vector<const std::string*> view(n);
     for (size_t i = 0; i < n; ++i) view[i] = &contents[i];
 
@@ -571,7 +614,7 @@ std::string ObjectStore::writeObject(const std::string& type, const std::string&
 std::string ObjectStore::writeTree(const std::string& directoryPath)
 {
     stats_ = StoreStats();
-    ++store_calls_;
+    store_calls_ = nextStoreCall();
     struct InTree { bool& f; InTree(bool& x) : f(x) { f = true; } ~InTree() { f = false; } } in_tree(in_write_tree_);
     const auto t_all = clk::now();
     if (!ensureHasher()) return {};
