@@ -254,7 +254,9 @@ int vit_bin_order_device(vit_hasher *h, int dev, const uint32_t *d_nblocks, uint
  * as for vit_hash_arena_device: object indices by length, vit_bin_order) lets the 64
  * lanes of a wave take objects of similar length, which end together.  On first use the
  * library allocates 181 KiB of device memory per object in flight (option
- * "deflate_lanes", default 65536: 11.9 GB) and keeps it with the queue. */
+ * "deflate_lanes", default 65536: 11.9 GB) and keeps it with the queue; launches
+ * on one queue share it, so the library makes each wait for the one before it,
+ * whatever streams they are on. */
 int vit_deflate_arena_device(vit_hasher *h, int dev, const void *d_arena, uint64_t arena_bytes,
                              const uint64_t *d_offsets, const uint32_t *d_nblocks,
                              const uint32_t *d_order, uint64_t n,

@@ -72,3 +72,25 @@ def test_device_resident_arena_streams_and_the_files_they_make(hasher):
         assert plain[i] == zlib.compress(_framed("blob", data), 6), i
         assert zlib.decompress(plain[i]) == _framed("blob", data)
     assert hasher.device_status() == 0
+
+
+def test_launches_on_two_streams_take_turns_with_the_queues_workspace(hasher):
+    """Two vit_deflate_arena_device calls on different streams, neither waited for: they share the queue's tables, so
+    the library orders them; both give the streams they give alone."""
+    import torch
+    import vit_amd
+    n = 40_000
+    batches, framed = [], []
+    for seed in (0x5EED00AC, 0x5EED00AD):
+        lens = np.random.default_rng(seed & 0xFF).integers(1000, 6000, n).astype(np.uint64)
+        batches.append(hasher.synth_arena("blob", seed, 0, n, 0, lens=lens))
+        framed.append([int(l) + vit_amd.header_len("blob", int(l)) for l in lens])
+    alone = [hasher.deflate_device(b, f)[0] for b, f in zip(batches, framed)]
+    streams = [torch.cuda.Stream(device=0), torch.cuda.Stream(device=0)]
+    hasher.sync(0)
+    launched = [hasher.deflate_device_launch(b, f, stream=s.cuda_stream) for b, f, s in zip(batches, framed, streams)]
+    torch.cuda.synchronize(0)
+    hasher.sync(0)
+    for k in range(2):
+        assert hasher.deflate_device_collect(launched[k]) == alone[k], k
+    assert hasher.device_status() == 0

@@ -82,6 +82,8 @@ struct Queue {
     void* sort_scratch = nullptr; size_t sort_scratch_bytes = 0;   // vit_bin_order_device
     uint8_t* z_workspace = nullptr; uint32_t z_lanes = 0;          // vit_deflate_arena_device: tables of the objects in flight
     void* z_tables = nullptr;                                      // ... and zlib's constant tables
+    hipEvent_t z_done = nullptr;                                   // ... and the end of the last launch that used them: the next one, on
+                                                                   // whatever stream, waits for it (one workspace per queue)
     uint8_t* z_out = nullptr; uint64_t z_out_cap = 0;              // vit_deflate_objects: a chunk's streams on the device
     uint8_t* z_meta_d = nullptr; uint8_t* z_meta_h = nullptr; uint64_t z_meta_cap = 0;   // ... their offsets and lengths (12 bytes per object)
     std::vector<hipEvent_t> timing;                       // pool for vit_time_hash_device
@@ -830,6 +832,7 @@ void vit_hasher_destroy(vit_hasher* h)
         if (q.sort_scratch) (void)hipFree(q.sort_scratch);
         if (q.z_workspace) (void)hipFree(q.z_workspace);
         if (q.z_tables) (void)hipFree(q.z_tables);
+        if (q.z_done) (void)hipEventDestroy(q.z_done);
         if (q.z_out) (void)hipFree(q.z_out);
         if (q.z_meta_d) (void)hipFree(q.z_meta_d);
         if (q.z_meta_h) (void)hipHostFree(q.z_meta_h);
@@ -1326,8 +1329,9 @@ static int ensure_deflate(vit_hasher* h, Queue& q)
         HIP_TRY(h, hipMalloc(&q.z_tables, host.size()));
         HIP_TRY(h, hipMemcpy(q.z_tables, host.data(), host.size(), hipMemcpyHostToDevice));
     }
+    if (!q.z_done) HIP_TRY(h, hipEventCreateWithFlags(&q.z_done, hipEventDisableTiming));
     if (q.z_lanes != h->deflate_lanes) {
-        for (hipStream_t st : q.stream) HIP_TRY(h, hipStreamSynchronize(st));
+        HIP_TRY(h, hipDeviceSynchronize());               // a launch on a caller's stream may still be using the old workspace
         if (q.z_workspace) { HIP_TRY(h, hipFree(q.z_workspace)); q.z_workspace = nullptr; q.z_lanes = 0; }
         HIP_TRY(h, hipMalloc(reinterpret_cast<void**>(&q.z_workspace), vit::deflate_workspace_bytes(h->deflate_lanes)));
         q.z_lanes = h->deflate_lanes;
@@ -1352,7 +1356,10 @@ int vit_deflate_arena_device(vit_hasher* h, int dev, const void* d_arena, uint64
     b.offsets = d_offsets; b.nblocks = d_nblocks; b.n = uint32_t(n); b.order = d_order;
     b.out = d_out; b.out_off = d_out_offsets; b.out_len = d_out_lens;
     b.workspace = q->z_workspace; b.tables_raw = q->z_tables; b.status = q->d_status;
-    HIP_TRY(h, vit::launch_deflate(b, q->z_lanes, stream ? static_cast<hipStream_t>(stream) : q->stream[0]));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : q->stream[0];
+    HIP_TRY(h, hipStreamWaitEvent(s, q->z_done, 0));      // launches share the queue's workspace: one after the other
+    HIP_TRY(h, vit::launch_deflate(b, q->z_lanes, s));
+    HIP_TRY(h, hipEventRecord(q->z_done, s));
     return VIT_OK;
 }
 
@@ -1450,7 +1457,9 @@ int vit_deflate_objects(vit_hasher* h, const char* type, const uint8_t* const* d
         b.order = binned ? s.d_order : nullptr;
         b.out = q.z_out; b.out_off = d_zoff; b.out_len = d_zlen;
         b.workspace = q.z_workspace; b.tables_raw = q.z_tables; b.status = q.d_status;
+        HIP_TRY(h, hipStreamWaitEvent(stream, q.z_done, 0));
         HIP_TRY(h, vit::launch_deflate(b, q.z_lanes, stream));
+        HIP_TRY(h, hipEventRecord(q.z_done, stream));
         HIP_TRY(h, hipMemcpyAsync(out + out_lo, q.z_out, out_hi - out_lo, hipMemcpyDeviceToHost, stream));
         HIP_TRY(h, hipMemcpyAsync(h_zlen, d_zlen, cnt * 4, hipMemcpyDeviceToHost, stream));
         HIP_TRY(h, hipStreamSynchronize(stream));

@@ -268,10 +268,9 @@ class Hasher:
         self.sync(batch["dev"])
         return batch["digests"].download(np.uint8, 20 * batch["n"]).reshape(-1, 20)
 
-    def deflate_device(self, batch, framed_lens, order=None):
-        """zlib streams of a batch from synth_arena() (vit_deflate_arena_device).  framed_lens: header + content
-        length per object (sizes the output).  Returns (list of bytes, seconds on the device)."""
-        import time
+    def deflate_device_launch(self, batch, framed_lens, order=None, stream=None):
+        """Queue vit_deflate_arena_device for a batch from synth_arena() on `stream` (a hipStream_t as an integer;
+        None = the queue's own) and return what deflate_device_collect needs; nothing is waited for."""
         n = batch["n"]
         lib = self.lib
         cap = np.array([max(lib.vit_deflate_bound(int(L)), 16) for L in framed_lens], dtype=np.uint64)
@@ -280,17 +279,30 @@ class Hasher:
         d_out = self.alloc(int(off[-1]) + 16, batch["dev"])
         d_off = self.alloc(8 * n, batch["dev"]).upload(off[:n].copy())
         d_len = self.alloc(4 * n, batch["dev"])
-        self.sync(batch["dev"])
-        t0 = time.perf_counter()
         self._check(lib.vit_deflate_arena_device(self.handle, batch["dev"], batch["arena"].ptr, batch["arena_bytes"],
                                                  batch["offsets"].ptr, batch["nblocks"].ptr,
                                                  order.ptr if order is not None else None, n, d_out.ptr, d_off.ptr,
-                                                 d_len.ptr, None))
+                                                 d_len.ptr, C.c_void_p(stream) if stream else None))
+        return {"n": n, "off": off, "d_out": d_out, "d_off": d_off, "d_len": d_len, "order": order}
+
+    @staticmethod
+    def deflate_device_collect(launched):
+        """The streams of a finished deflate_device_launch (the caller has synchronised): list of bytes."""
+        n, off = launched["n"], launched["off"]
+        lens = launched["d_len"].download(np.uint32, 4 * n)
+        raw = launched["d_out"].download(np.uint8, int(off[-1]))
+        return [raw[int(off[i]):int(off[i]) + int(lens[i])].tobytes() for i in range(n)]
+
+    def deflate_device(self, batch, framed_lens, order=None):
+        """zlib streams of a batch from synth_arena() (vit_deflate_arena_device).  framed_lens: header + content
+        length per object (sizes the output).  Returns (list of bytes, seconds on the device)."""
+        import time
+        self.sync(batch["dev"])
+        t0 = time.perf_counter()
+        launched = self.deflate_device_launch(batch, framed_lens, order)
         self.sync(batch["dev"])
         dt = time.perf_counter() - t0
-        lens = d_len.download(np.uint32, 4 * n)
-        raw = d_out.download(np.uint8, int(off[-1]))
-        return [raw[int(off[i]):int(off[i]) + int(lens[i])].tobytes() for i in range(n)], dt
+        return self.deflate_device_collect(launched), dt
 
     def deflate_objects(self, type_, blobs):
         """zlib streams of objects in host memory (vit_deflate_objects).  Returns (list of bytes, b'' where the
