@@ -9,7 +9,12 @@
 #include <random>
 #include <vector>
 #include <string>
-struct PtrIn { const uint8_t* p; uint8_t operator()(uint32_t i) const { return p[i]; } };
+struct PtrIn {
+    const uint8_t* p; uint32_t n;
+    uint8_t operator()(uint32_t i) const { return p[i]; }
+    // bytes i..i+3, the first in the top byte; what lies beyond the input is the caller's to mask
+    uint32_t be32(uint32_t i) const { uint32_t w = 0; for (uint32_t k = 0; k < 4; ++k) w = (w << 8) | (i + k < n ? p[i + k] : 0xEEu); return w; }
+};
 int main(int argc, char** argv) {
     int rounds = argc > 1 ? atoi(argv[1]) : 2000;
     zd::Tables t; zd::make_tables(t);
@@ -41,7 +46,7 @@ int main(int argc, char** argv) {
         std::vector<uint8_t> out(zd::bound(n));
         const uint32_t st = r % 2 ? 3 : 1;                     // the arrays strided as the GPU lanes interleave theirs, and plain
         zd::Work w{{head.data(), st}, {prev.data(), st}, {dbuf.data(), st}, {lbuf.data(), st}, small.data() + (r % 3), heap.data() + (r % 4), uint32_t(r % 2 ? 5 : 1), out.data(), uint32_t(out.size())};
-        d.in = PtrIn{in.data()};
+        d.in = PtrIn{in.data(), n};
         uint32_t got = d.run(&t, w, n);
         total += n;
         if (got != zl || memcmp(out.data(), z.data(), zl)) {

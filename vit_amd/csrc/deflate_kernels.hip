@@ -24,6 +24,14 @@ namespace {
 struct ArenaBytes {
     const uint8_t* p;
     __host__ __device__ uint8_t operator()(uint32_t i) const { return p[i ^ 3u]; }
+    // Bytes i..i+3 of the message, the first in the top byte: the arena's dwords are the message's big-endian words, so
+    // two aligned loads and a shift.  Reads up to byte (i | 3) + 4 of the slot: within the padding for every i < n.
+    __host__ __device__ uint32_t be32(uint32_t i) const
+    {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(p) + (i >> 2);
+        const uint64_t both = (uint64_t)w[0] << 32 | w[1];
+        return (uint32_t)((both << ((i & 3u) * 8u)) >> 32);
+    }
 };
 
 }  // namespace

@@ -491,77 +491,131 @@ template <class In> struct Deflater {
             }
             return last_lit == uint32_t(kLitBufSize - 1);
         };
-        auto flush = [&](int last) {
-            s.last_lit = last_lit;
-            flush_block(block_start, strstart - block_start, last);
-            last_lit = 0;
-            block_start = strstart;
-        };
-        // longest_match: the longest earlier occurrence of the bytes at strstart among the chain from cur_match
-        auto longest_match = [&](uint32_t cur_match) -> uint32_t {
-            unsigned chain_length = kChain;
-            int best_len = int(prev_length);
-            int nice_match = kNice;
-            const uint32_t limit = strstart > uint32_t(kMaxDist) ? strstart - uint32_t(kMaxDist) : 0;
-            uint32_t scan_end1 = byte_at(strstart + uint32_t(best_len) - 1), scan_end = byte_at(strstart + uint32_t(best_len));
-            if (prev_length >= uint32_t(kGood)) chain_length >>= 2;
-            if (uint32_t(nice_match) > lookahead) nice_match = int(lookahead);
-            const uint32_t scan0 = byte_at(strstart), scan1 = byte_at(strstart + 1);
-            do {
-                if (byte_at(cur_match + uint32_t(best_len)) != scan_end || byte_at(cur_match + uint32_t(best_len) - 1) != scan_end1 ||
-                    byte_at(cur_match) != scan0 || byte_at(cur_match + 1) != scan1)
-                    continue;
-                // bytes 0 and 1 match, and byte 2 with them (same hash of three bytes, wide enough to tell);
-                // zlib resumes at byte 3, which comes to the same length
-                int len = 2;
-                while (len < kMaxMatch && byte_at(strstart + uint32_t(len)) == byte_at(cur_match + uint32_t(len))) ++len;
-                if (len > best_len) {
-                    match_start = cur_match;
-                    best_len = len;
-                    if (len >= nice_match) break;
-                    scan_end1 = byte_at(strstart + uint32_t(best_len) - 1);
-                    scan_end = byte_at(strstart + uint32_t(best_len));
-                }
-            } while ((cur_match = prev[int(cur_match & kWMask)]) > limit && --chain_length != 0);
-            if (uint32_t(best_len) <= lookahead) return uint32_t(best_len);
-            return lookahead;
+        // 4 input bytes from i on, the first in the top byte; zeros from the end of the input on (zlib's window
+        // is zeroed behind the input, and its comparisons may run into that)
+        auto word_at = [&](uint32_t i) -> uint32_t {
+            if (i >= n) return 0;
+            const uint32_t w = input.be32(i);
+            const uint32_t over = i + 4 > n ? i + 4 - n : 0;
+            return over ? w & (0xFFFFFFFFu << (8 * over)) : w;
         };
 
-        while (lookahead != 0) {
-            uint32_t hash_head = 0;
-            if (lookahead >= uint32_t(kMinMatch)) hash_head = insert(strstart);
-            prev_length = match_length; prev_match = match_start;
-            match_length = kMinMatch - 1;
-            if (hash_head != 0 && prev_length < uint32_t(kLazy) && strstart - hash_head <= uint32_t(kMaxDist)) {
-                match_length = longest_match(hash_head);
-                if (match_length <= 5 && match_length == uint32_t(kMinMatch) && strstart - match_start > uint32_t(kTooFar))
-                    match_length = kMinMatch - 1;
-            }
-            if (prev_length >= uint32_t(kMinMatch) && match_length <= prev_length) {
-                const uint32_t max_insert = strstart + lookahead - kMinMatch;
-                const bool bflush = tally(strstart - 1 - prev_match, prev_length - kMinMatch);
-                lookahead -= prev_length - 1;
-                prev_length -= 2;
-                do {
-                    if (++strstart <= max_insert) insert(strstart);
-                } while (--prev_length != 0);
-                match_available = false;
+        // The scan is deflate_slow with longest_match in line, laid out as ONE loop whose every turn does one unit
+        // of work: either the start of a position (INSERT_STRING; positions inside a match that has been emitted do
+        // nothing else) or ONE candidate of a hash chain, and then, when the position's search is over or there was
+        // none, zlib's choice between match, literal and waiting.  zlib nests three loops here (positions, chain,
+        // comparison; and a fourth that inserts the positions of an emitted match).  On a GPU the 64 lanes of a wave
+        // run 64 objects through this code together, and nested loops make every lane wait for the longest chain and
+        // the longest match among them at every step; in the flat form a lane with a long chain takes more turns and
+        // holds nobody up.  The candidate's link, its two bytes at the end of the best match so far and its first four
+        // bytes are loaded together, before any of them is looked at.
+        // Bytes off and off + 1 behind position base, of which `first` holds the first four: no load while they lie
+        // within those four (a search starts from a best length of 2, where most candidates are turned down).
+        auto pair_at = [&](uint32_t first, uint32_t base, uint32_t off) -> uint32_t {
+            return off <= 2 ? (first << (8 * off)) >> 16 : word_at(base + off) >> 16;
+        };
+
+        // zlib flushes a block from inside the scan when the symbol buffer is full.  Here the scan stops instead, the one
+        // flush below is done and the scan is entered again where it stopped: the block code is large, and in line at
+        // every place that may flush it is three times the rest of the kernel.
+        uint32_t skip = 0;                                               // positions still to insert of a match already emitted
+        bool searching = false;
+        uint32_t cur = 0, chain = 0, limit = 0, best_len = 0, nice = 0;  // longest_match's state
+        uint32_t scan_head = 0, scan_end2 = 0;                           // bytes 0..3 at strstart; bytes best_len-1, best_len
+        for (;;) {
+        bool full = false;
+        uint32_t flush_at = 0;
+        while ((strstart < n || searching) && !full) {
+            bool decide = false;
+            lookahead = n - strstart;
+            if (!searching) {
+                uint32_t hash_head = 0;
+                if (lookahead >= uint32_t(kMinMatch)) hash_head = insert(strstart);
+                if (skip != 0) { --skip; ++strstart; continue; }
+                prev_length = match_length; prev_match = match_start;
                 match_length = kMinMatch - 1;
-                strstart++;
-                if (bflush) flush(0);
-            } else if (match_available) {
-                const bool bflush = tally(0, byte_at(strstart - 1));
-                if (bflush) flush(0);
-                strstart++;
-                lookahead--;
-            } else {
-                match_available = true;
-                strstart++;
-                lookahead--;
+                if (hash_head != 0 && prev_length < uint32_t(kLazy) && strstart - hash_head <= uint32_t(kMaxDist)) {
+                    searching = true;
+                    cur = hash_head;
+                    chain = prev_length >= uint32_t(kGood) ? kChain >> 2 : kChain;
+                    best_len = prev_length;
+                    nice = uint32_t(kNice) > lookahead ? lookahead : uint32_t(kNice);
+                    limit = strstart > uint32_t(kMaxDist) ? strstart - uint32_t(kMaxDist) : 0;
+                    scan_head = word_at(strstart);
+                    scan_end2 = pair_at(scan_head, strstart, best_len - 1);
+                } else decide = true;
+            }
+            if (searching) {
+                const uint32_t next = prev[int(cur & kWMask)];
+                const uint32_t m_head = word_at(cur);
+                const uint32_t m_end2 = pair_at(m_head, cur, best_len - 1);
+                bool over = false;
+                uint32_t x = m_head ^ scan_head;
+                if (m_end2 == scan_end2 && (x >> 16) == 0) {
+                    // bytes 0 and 1 match, and byte 2 with them (same hash of three bytes, wide enough to tell);
+                    // zlib resumes at byte 3, which comes to the same length
+                    uint32_t len = 4;
+                    if (x) len = uint32_t(__builtin_clz(x)) >> 3;
+                    else {
+                        while (len < uint32_t(kMaxMatch)) {
+                            x = word_at(strstart + len) ^ word_at(cur + len);
+                            if (x) { len += uint32_t(__builtin_clz(x)) >> 3; break; }
+                            len += 4;
+                        }
+                        if (len > uint32_t(kMaxMatch)) len = kMaxMatch;
+                    }
+                    if (len > best_len) {
+                        match_start = cur;
+                        best_len = len;
+                        if (len >= nice) over = true;
+                        else scan_end2 = pair_at(scan_head, strstart, best_len - 1);
+                    }
+                }
+                if (!over) {
+                    cur = next;
+                    if (cur <= limit || --chain == 0) over = true;
+                }
+                if (over) {
+                    searching = false;
+                    match_length = best_len <= lookahead ? best_len : lookahead;
+                    if (match_length == uint32_t(kMinMatch) && strstart - match_start > uint32_t(kTooFar))
+                        match_length = kMinMatch - 1;
+                    decide = true;
+                }
+            }
+            if (decide) {
+                if (prev_length >= uint32_t(kMinMatch) && match_length <= prev_length) {
+                    // the match found at the position before stands: its remaining positions are inserted by the turns
+                    // that follow (zlib inserts them here and flushes after them; the flush reads neither table)
+                    const bool bflush = tally(strstart - 1 - prev_match, prev_length - kMinMatch);
+                    skip = prev_length - 2;
+                    const uint32_t next_start = strstart + prev_length - 1;
+                    match_available = false;
+                    match_length = kMinMatch - 1;
+                    if (bflush) { full = true; flush_at = next_start; }
+                    ++strstart;
+                } else if (match_available) {
+                    const bool bflush = tally(0, byte_at(strstart - 1));
+                    if (bflush) { full = true; flush_at = strstart; }
+                    ++strstart;
+                } else {
+                    match_available = true;
+                    ++strstart;
+                }
             }
         }
-        if (match_available) tally(0, byte_at(strstart - 1));
-        flush(1);
+        lookahead = n - strstart;
+        const int last = full ? 0 : 1;
+        if (last) {
+            if (match_available) tally(0, byte_at(strstart - 1));
+            flush_at = strstart;
+        }
+        s.last_lit = last_lit;
+        flush_block(block_start, flush_at - block_start, last);
+        last_lit = 0;
+        block_start = flush_at;
+        if (last) break;
+        }
 
         // adler32 of the input, big-endian
         uint32_t a = 1, b = 0;
