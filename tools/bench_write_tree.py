@@ -67,6 +67,48 @@ def make_c2(root, n_files):
     return n_files, n_files * 4096
 
 
+_TEXT = None
+
+
+def _text_pool():
+    """80 MB of text-like bytes (words drawn with a Zipf law), the same in every process."""
+    global _TEXT
+    if _TEXT is None:
+        rng = np.random.default_rng(12)
+        vocab = [bytes(rng.integers(97, 123, int(k)).astype(np.uint8)) for k in rng.integers(2, 10, 3000)]
+        vocab += [b"    ", b"\n", b"{", b"}", b"(", b")", b";", b"return ", b"const ", b"int ", b"if (", b"for ("]
+        pick = np.minimum(rng.zipf(1.3, 12_000_000), len(vocab)) - 1
+        _TEXT = b" ".join(vocab[int(k)] for k in pick)
+    return _TEXT
+
+
+def _c2text_part(args):
+    root, lo, hi = args
+    text = _text_pool()
+    rng = np.random.default_rng(lo + 1)
+    starts = rng.integers(0, len(text) - 4096, hi - lo)
+    for i in range(lo, hi):
+        d = os.path.join(root, "d%03d" % (i // 1000))
+        if i % 1000 == 0 or i == lo:
+            os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "f%07d.c" % i), "wb") as f:
+            s = int(starts[i - lo])
+            f.write(b"/* %07d */" % i + text[s:s + 4096 - 13])
+    return hi - lo
+
+
+def make_c2_text(root, n_files):
+    """The headline layout with text-like content: n files x 4,096 B that zlib brings down to about a third, where the
+    random blobs of make_c2 do not compress at all; 1,000 per directory."""
+    import multiprocessing as mp
+    procs = 8
+    cuts = [n_files * k // procs // 1000 * 1000 for k in range(procs)] + [n_files]
+    with mp.Pool(procs) as pool:
+        for part in pool.imap_unordered(_c2text_part, [(root, cuts[k], cuts[k + 1]) for k in range(procs)]):
+            pass
+    return n_files, n_files * 4096
+
+
 def make_c3(root, n_files):
     """Linux-kernel-like: lognormal sizes (median 4.5 KB, sigma 1.55) clipped to 32 MiB and rescaled to
     ~15 KB mean; ~n/16 directories, three levels; names avoid the cases where the reference and git differ."""
@@ -103,11 +145,12 @@ def run_vit(wt, args=()):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("config", choices=["c1", "c2", "c3"])
+    ap.add_argument("config", choices=["c1", "c2", "c2text", "c3"])
     ap.add_argument("--files", type=int, default=None, help="c2: default 1,000,000; c3: default 80,000")
     ap.add_argument("--git", action="store_true", help="also run real `git add -A && git write-tree` on the worktree")
     ap.add_argument("--dir", default=None, help="where to build the worktree (default: a temp dir, /dev/shm if present)")
     ap.add_argument("--skip-reference", action="store_true")
+    ap.add_argument("--host-deflate", action="store_true", help="also run `vit write-tree --host-deflate` (zlib on host threads only)")
     ap.add_argument("--levels", type=int, nargs="*", default=[],
                     help="also run `vit write-tree --deflate-level=N` for these zlib levels (same ids, other stored bytes)")
     ap.add_argument("--make-only", action="store_true", help="build the worktree under --dir/wt and stop (bench.py's generator)")
@@ -116,7 +159,7 @@ def main():
         wt = os.path.join(a.dir, "wt")
         os.makedirs(wt, exist_ok=True)
         n, total = (make_c1(wt) if a.config == "c1" else make_c2(wt, a.files or 1_000_000) if a.config == "c2"
-                    else make_c3(wt, a.files or 80000))
+                    else make_c2_text(wt, a.files or 200_000) if a.config == "c2text" else make_c3(wt, a.files or 80000))
         print(json.dumps({"files": n, "bytes": total}))
         return
     base = a.dir or tempfile.mkdtemp(prefix="vitwt_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
@@ -128,6 +171,8 @@ def main():
             n, total = make_c1(wt)
         elif a.config == "c2":
             n, total = make_c2(wt, a.files or 1_000_000)
+        elif a.config == "c2text":
+            n, total = make_c2_text(wt, a.files or 200_000)
         else:
             n, total = make_c3(wt, a.files or 80000)
         gen_s = time.perf_counter() - t0
@@ -173,6 +218,11 @@ def main():
                                  "objects_per_s": round((nb + nt) / dt, 1),
                                  "ids_only_wall_s": round(dt2, 3), "ids_only_stats": stats2}
         out["match"] = bool(root == want.hex() == root2)
+        if a.host_deflate:
+            shutil.rmtree(os.path.join(wt, ".git"), ignore_errors=True)
+            r4, dt4, st4 = run_vit(wt, ["--host-deflate"])
+            out["gpu_write_tree_host_deflate"] = {"root": r4, "wall_s": round(dt4, 3), "stats": st4}
+            out["match"] = out["match"] and r4 == root
         for level in a.levels:
             shutil.rmtree(os.path.join(wt, ".git"), ignore_errors=True)
             r3, dt3, st3 = run_vit(wt, ["--deflate-level=%d" % level])

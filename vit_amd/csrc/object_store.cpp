@@ -672,11 +672,31 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
     auto mark = [&, t_all](const char* what, size_t k) {
         if (timeline) std::fprintf(stderr, "[vit timeline] %8.1f ms  batch %zu %s\n", since(t_all) * 1e3, k, what);
     };
+    // Of a batch's small objects, the share (in sixteenths) that the device deflates; the host threads do the rest next
+    // to their file operations.  How fast a lane deflates depends on the content (incompressible bytes: a position has
+    // no hash chain to walk; text: several candidates per position, three to four times the work), how fast the host
+    // threads are on the machine and its file system, so the share follows what the pipeline waits for: when a slot is
+    // needed again and its batch is still with the device, the device gets less of the next batches; when the device is
+    // long done and the host threads are still storing, it gets more.
+    std::atomic<int> device_share{16};
+    if (const char* e = std::getenv("VIT_DEVICE_SHARE")) device_share = std::max(1, std::min(16, std::atoi(e)));
+    const bool adapt_share = std::getenv("VIT_DEVICE_SHARE") == nullptr;
     auto finish = [&](Slot& s) {                          // wait for a slot's stores; false if any failed
-        if (s.deflate.valid()) { s.deflate.wait(); s.deflate = std::shared_future<void>(); }
+        double waited_device = 0;
+        if (s.deflate.valid()) {
+            const auto t = clk::now();
+            s.deflate.wait();
+            s.deflate = std::shared_future<void>();
+            waited_device = since(t);
+        }
         if (!s.store) return true;
+        const auto t = clk::now();
         workers.wait(s.store);
         s.store.reset();
+        if (adapt_share) {
+            if (waited_device > 0.005) device_share = std::max(4, device_share.load() - 2);
+            else if (since(t) > 0.005 && device_share < 16) device_share = device_share.load() + 1;
+        }
         mark("a slot's objects are stored", size_t(&s - slot));
         return storeFinished(s.outcome);
     };
@@ -735,27 +755,34 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
         if (on_device) {
             if (!deflater) deflater.reset(new SerialWorker());
             Slot* sp = &s;
-            s.deflate = deflater->post([this, sp, k, &mark] {
+            s.deflate = deflater->post([this, sp, k, &mark, &device_share] {
                 Slot& s = *sp;
                 mark("deflate begins", k);
                 DeviceStreams dz{nullptr, nullptr, nullptr};
                 try {
                     const auto t = clk::now();
-                    const size_t cnt = s.contents.size();
+                    const size_t all = s.contents.size();
+                    const size_t share = size_t(device_share.load());
+                    std::vector<uint32_t> pick;                        // the device's objects: `share` of every sixteen
+                    pick.reserve(all);
+                    for (size_t i = 0; i < all; ++i) if (i % 16 < share) pick.push_back(uint32_t(i));
+                    const size_t cnt = pick.size();
                     std::vector<const uint8_t*> ptr(cnt);
                     std::vector<uint64_t> len(cnt);
-                    for (size_t i = 0; i < cnt; ++i) { ptr[i] = reinterpret_cast<const uint8_t*>(s.contents[i].data()); len[i] = s.contents[i].size(); }
+                    for (size_t j = 0; j < cnt; ++j) { const std::string& c = s.contents[pick[j]]; ptr[j] = reinterpret_cast<const uint8_t*>(c.data()); len[j] = c.size(); }
                     const uint64_t need = vit_deflate_out_bytes(deflate_hasher_, "blob", len.data(), cnt);
                     if (need > s.zcap) {
                         if (s.zbuf) { vit_arena_free(hasher_, s.zbuf); s.zbuf = nullptr; s.zcap = 0; }
                         if (vit_arena_alloc(hasher_, need + need / 4, &s.zbuf) == VIT_OK) s.zcap = need + need / 4;
                     }
-                    s.zoff.assign(cnt, 0); s.zlen.assign(cnt, 0);
+                    std::vector<uint64_t> off(cnt, 0);
+                    std::vector<uint32_t> zl(cnt, 0);
+                    s.zoff.assign(all, 0); s.zlen.assign(all, 0);
                     if (need && s.zbuf &&
                         vit_deflate_objects(deflate_hasher_, "blob", ptr.data(), len.data(), cnt, static_cast<uint8_t*>(s.zbuf), s.zcap,
-                                            s.zoff.data(), s.zlen.data()) == VIT_OK) {
+                                            off.data(), zl.data()) == VIT_OK) {
+                        for (size_t j = 0; j < cnt; ++j) { s.zoff[pick[j]] = off[j]; s.zlen[pick[j]] = zl[j]; stats_.device_deflated += zl[j] != 0; }
                         dz = DeviceStreams{static_cast<const uint8_t*>(s.zbuf), s.zoff.data(), s.zlen.data()};
-                        for (uint32_t l : s.zlen) stats_.device_deflated += l != 0;
                     } else if (need) {
                         std::cerr << "vit: deflate on the device failed (" << vit_last_error(deflate_hasher_) << "); this batch on host threads\n";
                     }
