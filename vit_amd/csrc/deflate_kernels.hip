@@ -11,8 +11,10 @@
 // workspace per wave with the 64 lanes' entries interleaved.  A wave takes 64 objects at a time
 // and moves on to its next 64 when the longest of them is done.  The work is bound by scattered
 // two-byte accesses to those tables (the scan, and the Huffman heap of every block), i.e. by the
-// memory system's transaction rate, not by arithmetic: about 10 us per input byte and lane,
-// 1.7 M objects of 4 KiB per second over the chip.
+// memory system's transaction rate, not by arithmetic: every lane's object, tables and position are
+// its own, so a wave's memory instruction touches up to 64 cache lines.  Incompressible content runs
+// at 8-11 us per input byte and lane (1.4-2 M objects of 4 KiB per second over the chip), text-like
+// content, whose positions have hash chains to walk, at about four times that.
 #include "kernels.h"
 #include "zdeflate.h"
 
