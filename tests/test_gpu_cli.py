@@ -107,6 +107,14 @@ def test_device_deflate_stores_the_files_the_library_would(oracle, golden_trees,
         q = vit(host, "write-tree", "--stats", "--host-deflate")
         assert " s (0 objects)" in q.stderr.decode()
         assert stored_objects(host).keys() == stored_objects(wt).keys()
+        # five sixteenths of every batch on the device, the rest on host threads: the same files again
+        part = fresh_copy(worktrees[name], tmp_path / ("pd_" + name))
+        r = vit(part, "write-tree", "--stats", env=dict(force, VIT_DEVICE_SHARE="5"))
+        some = int(r.stderr.decode().split(" s (")[1].split(" objects)")[0])
+        assert 0 < some < done, (some, done)
+        for d in os.listdir(ref_dir):
+            for f in os.listdir(ref_dir / d):
+                assert open(os.path.join(part, ".git", "objects", d, f), "rb").read() == open(ref_dir / d / f, "rb").read(), d + f
 
 
 def test_write_tree_with_fewer_descriptors_than_fanout_directories(golden_trees, worktrees, tmp_path):
