@@ -117,6 +117,20 @@ def test_device_deflate_stores_the_files_the_library_would(oracle, golden_trees,
                 assert open(os.path.join(part, ".git", "objects", d, f), "rb").read() == open(ref_dir / d / f, "rb").read(), d + f
 
 
+def test_device_deflate_failing_leaves_the_work_to_the_host(golden_trees, worktrees, tmp_path):
+    """vit_deflate_objects failing (injected) costs nothing but a message, once: the batch and those after it are deflated
+    by host threads, ids and stored objects as ever."""
+    name = [k for k in golden_trees if golden_trees[k].get("spec") == "skew"][0]
+    wt = fresh_copy(worktrees[name], tmp_path / "ddfail")
+    p = vit(wt, "write-tree", "--stats", env={"VIT_DEVICE_DEFLATE": "1", "VIT_DEVICE_DEFLATE_MIN": "1", "VIT_BATCH_MB": "8",
+                                              "VIT_DEBUG_FAIL_DEFLATE": "1"})
+    assert p.stdout.decode().strip() == golden_trees[name]["root"]
+    err = p.stderr.decode()
+    assert err.count("deflate on the device failed") == 1 and " s (0 objects)" in err, err
+    objs = stored_objects(wt)
+    assert set(golden_trees[name]["blob_ids"]) <= set(objs) and set(golden_trees[name]["tree_ids"]) <= set(objs)
+
+
 def test_write_tree_with_fewer_descriptors_than_fanout_directories(golden_trees, worktrees, tmp_path):
     """The storing threads keep a handle per objects/xx directory; where the descriptor limit is below the 256 of
     them (plus what the runtime holds), they give handles back and carry on: same id, every object stored."""

@@ -135,6 +135,7 @@ struct vit_hasher {
     double host_bias = 1;                                 // see the end of hash_batch
     uint64_t calibrate_ns = 0;
     uint64_t fail_at_chunk = 0;                           // fault injection for tests: 0 = off
+    bool fail_deflate = false;                            // option debug_fail_deflate: vit_deflate_objects fails (tests)
     uint64_t deflate_max_bytes = 16384;                   // vit_deflate_objects: longer objects (framed) are left to the host
     uint32_t deflate_lanes = 65536;                       // objects the deflate kernel keeps in flight (181 KiB of device memory each)
     std::atomic<uint64_t> objects_gpu{0}, objects_host{0}, bytes_host{0}, blocks_gpu{0}, bytes_h2d{0}, launches{0};
@@ -873,6 +874,7 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     else if (k == "pack_rate") rate(h->pack_rate, h->pack_fixed);
     else if (k == "host_bias_percent") h->host_bias = value ? double(value) / 100.0 : 1.0;
     else if (k == "debug_fail_at_chunk") h->fail_at_chunk = value;
+    else if (k == "debug_fail_deflate") h->fail_deflate = value != 0;
     else if (k == "deflate_max_bytes") h->deflate_max_bytes = std::min<uint64_t>(value, vit::deflate_max_input());
     else if (k == "deflate_lanes") h->deflate_lanes = uint32_t(std::min<uint64_t>(std::max<uint64_t>(value, 64), 1u << 20) / 64 * 64);
     else if (k == "sched_waves") h->sched_waves = uint32_t(value > 8 ? 8 : value);
@@ -1380,6 +1382,7 @@ int vit_deflate_objects(vit_hasher* h, const char* type, const uint8_t* const* d
     VIT_NOEXCEPT_BEGIN
     Queue& q = h->queues[0];
     drain(q);
+    if (h->fail_deflate) return fail(h, VIT_ERR_HIP, "failure injected (option debug_fail_deflate)");
     HIP_TRY(h, hipSetDevice(q.device));
     if (int rc = ensure_deflate(h, q)) return rc;
 

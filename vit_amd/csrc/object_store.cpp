@@ -419,6 +419,7 @@ bool ObjectStore::ensureDeflateHasher()
     }
     vit_hasher_set_option(deflate_hasher_, "pack_threads", uint64_t(std::max(2, io_threads_ / 4)));
     if (const char* e = std::getenv("VIT_DEVICE_DEFLATE_MAX")) vit_hasher_set_option(deflate_hasher_, "deflate_max_bytes", std::strtoull(e, nullptr, 10));
+    if (std::getenv("VIT_DEBUG_FAIL_DEFLATE")) vit_hasher_set_option(deflate_hasher_, "debug_fail_deflate", 1);   // tests
     return true;
 }
 
@@ -678,6 +679,7 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
     // threads are on the machine and its file system, so the share follows what the pipeline waits for: when a slot is
     // needed again and its batch is still with the device, the device gets less of the next batches; when the device is
     // long done and the host threads are still storing, it gets more.
+    std::atomic<bool> device_failed{false};
     std::atomic<int> device_share{16};
     if (const char* e = std::getenv("VIT_DEVICE_SHARE")) device_share = std::max(1, std::min(16, std::atoi(e)));
     const bool adapt_share = std::getenv("VIT_DEVICE_SHARE") == nullptr;
@@ -750,12 +752,12 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
         if (may_device) {
             uint64_t small = 0;
             for (const std::string& c : s.contents) small += c.size() + 32 <= device_max_bytes;
-            on_device = small >= device_min_objects && ensureDeflateHasher();
+            on_device = small >= device_min_objects && !device_failed.load() && ensureDeflateHasher();
         }
         if (on_device) {
             if (!deflater) deflater.reset(new SerialWorker());
             Slot* sp = &s;
-            s.deflate = deflater->post([this, sp, k, &mark, &device_share] {
+            s.deflate = deflater->post([this, sp, k, &mark, &device_share, &device_failed] {
                 Slot& s = *sp;
                 mark("deflate begins", k);
                 DeviceStreams dz{nullptr, nullptr, nullptr};
@@ -784,7 +786,10 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
                         for (size_t j = 0; j < cnt; ++j) { s.zoff[pick[j]] = off[j]; s.zlen[pick[j]] = zl[j]; stats_.device_deflated += zl[j] != 0; }
                         dz = DeviceStreams{static_cast<const uint8_t*>(s.zbuf), s.zoff.data(), s.zlen.data()};
                     } else if (need) {
-                        std::cerr << "vit: deflate on the device failed (" << vit_last_error(deflate_hasher_) << "); this batch on host threads\n";
+                        // once is enough: the batches that follow go to the host threads without trying (no memory for
+                        // the tables on a GPU that others use, a device error)
+                        if (!device_failed.exchange(true))
+                            std::cerr << "vit: deflate on the device failed (" << vit_last_error(deflate_hasher_) << "); zlib on host threads from here on\n";
                     }
                     stats_.device_deflate_s += since(t);
                 } catch (const std::exception&) { dz = DeviceStreams{nullptr, nullptr, nullptr}; }      // out of memory: host threads do the batch
