@@ -13,11 +13,14 @@ struct PtrIn {
     const uint8_t* p; uint32_t n;
     uint8_t operator()(uint32_t i) const { return p[i]; }
     // bytes i..i+3, the first in the top byte; what lies beyond the input is the caller's to mask
+    uint32_t be32a(uint32_t i) const { return be32(i); }    // the same from a multiple of four
     uint32_t be32(uint32_t i) const { uint32_t w = 0; for (uint32_t k = 0; k < 4; ++k) w = (w << 8) | (i + k < n ? p[i + k] : 0xEEu); return w; }
 };
 int main(int argc, char** argv) {
     int rounds = argc > 1 ? atoi(argv[1]) : 2000;
     zd::Tables t; zd::make_tables(t);
+    for (uint32_t lc = 0; lc < 256; ++lc) if (zd::length_code_of(lc) != t.length_code[lc]) { printf("length_code_of(%u)\n", lc); return 3; }
+    for (uint32_t d = 0; d < 32768; ++d) if (zd::dist_code_of(d) != (d < 256 ? t.dist_code[d] : t.dist_code[256 + (d >> 7)])) { printf("dist_code_of(%u)\n", d); return 3; }
     std::vector<uint16_t> head(zd::kHashSize * 3), prev(32768 * 3), dbuf(zd::kLitBufSize * 3);
     std::vector<uint8_t> lbuf(zd::kLitBufSize * 3);
     std::vector<uint16_t> small(zd::kSmallEntries * 5);

@@ -28,6 +28,8 @@ struct ArenaBytes {
     __host__ __device__ uint8_t operator()(uint32_t i) const { return p[i ^ 3u]; }
     // Bytes i..i+3 of the message, the first in the top byte: the arena's dwords are the message's big-endian words, so
     // one load of two dwords and a shift.  Reads up to byte (i | 3) + 4 of the slot: within the padding for every i < n.
+    // The same from a multiple of four: the arena's dword itself.
+    __host__ __device__ uint32_t be32a(uint32_t i) const { return reinterpret_cast<const uint32_t*>(p)[i >> 2]; }
     __host__ __device__ uint32_t be32(uint32_t i) const
     {
         struct __attribute__((packed, aligned(4))) Pair { uint64_t v; };          // one 8-byte load on a 4-byte boundary

@@ -102,6 +102,22 @@ inline void make_tables(Tables& t)
     for (n = 0; n < 30; n++) t.static_dcode[n] = uint16_t(bi_reverse_host(unsigned(n), 5));
 }
 
+// Tables::length_code and Tables::dist_code worked out instead of looked up (the scan counts a symbol's codes at every
+// match; a table costs it a memory round trip each).  lc = match length - 3; d = distance - 1.
+ZD_FN uint32_t length_code_of(uint32_t lc)
+{
+    if (lc < 8) return lc;
+    if (lc == 255) return 28;
+    const uint32_t b = 31u - uint32_t(__builtin_clz(lc));
+    return 4 * (b - 1) + ((lc >> (b - 2)) & 3u);
+}
+ZD_FN uint32_t dist_code_of(uint32_t d)
+{
+    if (d < 4) return d;
+    const uint32_t b = 31u - uint32_t(__builtin_clz(d));
+    return 2 * b + ((d >> (b - 1)) & 1u);
+}
+
 // A small array of 16-bit entries whose elements lie `stride` entries apart: on the GPU the 64
 // lanes of a wave interleave theirs (stride 64, lane l starting at entry l), so that lanes
 // reading the same index of their own arrays — the common case in the tree code — touch one
@@ -110,6 +126,27 @@ struct Arr16 {
     uint16_t* p; uint32_t stride;
     ZD_FN uint16_t& operator[](int i) const { return p[uint32_t(i) * stride]; }
 };
+// ++a[i] for a counter nothing reads before counts_settled(): on the GPU an atomic add that returns nothing (on the dword
+// that holds the entry and a neighbouring lane's), so the lane does not wait for the memory round trip a load, add and
+// store would cost it at every symbol.  Counts stay below 2^14 (a block's symbols), so nothing carries between the halves.
+ZD_FN void bump(const Arr16& a, int i)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint16_t* const e = &a[i];
+    const uintptr_t at = reinterpret_cast<uintptr_t>(e);
+    __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(at & ~uintptr_t(3)), (at & 2u) ? 0x10000u : 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+#else
+    a[i]++;
+#endif
+}
+// Before the counters bumped so far are read: the adds have been done and this lane's loads see them.
+ZD_FN void counts_settled()
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+#endif
+}
 struct Arr32 {
     uint32_t* p; uint32_t stride;
     ZD_FN uint32_t& operator[](int i) const { return p[uint32_t(i) * stride]; }
@@ -467,8 +504,6 @@ template <class In> struct Deflater {
         const Arr16 head = work.head, prev = work.prev, d_buf = work.d_buf;
         const Arr8 l_buf = work.l_buf;
         const Arr16 lt_fc = s.lt_fc, dt_fc = s.dt_fc;
-        const uint8_t* const length_code = tables->length_code;
-        const uint8_t* const dist_code = tables->dist_code;
         auto byte_at = [&](uint32_t i) -> uint32_t { return i < n ? uint32_t(input(i)) : 0u; };
 
         uint32_t strstart = 0, lookahead = n, block_start = 0, last_lit = 0;
@@ -477,8 +512,19 @@ template <class In> struct Deflater {
         uint32_t ins_h = 0;
         if (n >= 2) ins_h = ((byte_at(0) << kHashShift) ^ byte_at(1)) & kHashMask;
 
+        // The bytes around the scan's position, in a register: input bytes [wpos - 8, wpos), the last in the lowest byte,
+        // topped up four at a time from whole words of the input.  The hash wants the byte two ahead of every position, a
+        // literal the byte one behind, a search the four from the position on: one load in four positions instead of
+        // one to three at each, and none of them in the way of what depends on them.
+        uint64_t win = 0;
+        uint32_t wpos = 0;
+        auto top_up = [&](uint32_t upto) {                              // bytes below `upto` (<= n + 3) are in the window after this
+            while (wpos < upto) { win = (win << 32) | input.be32a(wpos); wpos += 4; }
+        };
+        auto win_byte = [&](uint32_t j) -> uint32_t { return uint32_t(win >> (8 * (wpos - 1 - j))) & 0xffu; };   // wpos - 8 <= j < wpos
+
         auto insert = [&](uint32_t str) -> uint32_t {                   // INSERT_STRING; returns the previous head
-            ins_h = ((ins_h << kHashShift) ^ byte_at(str + 2)) & kHashMask;
+            ins_h = ((ins_h << kHashShift) ^ win_byte(str + 2)) & kHashMask;
             const uint32_t h = head[int(ins_h)];
             prev[int(str & kWMask)] = uint16_t(h);
             head[int(ins_h)] = uint16_t(str);
@@ -488,11 +534,10 @@ template <class In> struct Deflater {
             d_buf[int(last_lit)] = uint16_t(dist);
             l_buf[int(last_lit)] = uint8_t(lc);
             last_lit++;
-            if (dist == 0) lt_fc[int(lc)]++;
+            if (dist == 0) bump(lt_fc, int(lc));
             else {
-                dist--;
-                lt_fc[int(length_code[lc]) + kLiterals + 1]++;
-                dt_fc[int(dist < 256 ? dist_code[dist] : dist_code[256 + (dist >> 7)])]++;
+                bump(lt_fc, int(length_code_of(lc)) + kLiterals + 1);
+                bump(dt_fc, int(dist_code_of(dist - 1)));
             }
             return last_lit == uint32_t(kLitBufSize - 1);
         };
@@ -535,10 +580,12 @@ template <class In> struct Deflater {
             lookahead = n - strstart;
             if (!searching) {
                 uint32_t hash_head = 0;
+                top_up(strstart + 4);
                 if (lookahead >= uint32_t(kMinMatch)) hash_head = insert(strstart);
                 if (skip != 0) {
                     --skip; ++strstart;
                     for (int rep = 1; rep < kSkipPerTurn && skip != 0; ++rep) {
+                        top_up(strstart + 4);
                         if (n - strstart >= uint32_t(kMinMatch)) insert(strstart);
                         --skip; ++strstart;
                     }
@@ -553,7 +600,7 @@ template <class In> struct Deflater {
                     best_len = prev_length;
                     nice = uint32_t(kNice) > lookahead ? lookahead : uint32_t(kNice);
                     limit = strstart > uint32_t(kMaxDist) ? strstart - uint32_t(kMaxDist) : 0;
-                    scan_head = word_at(strstart);
+                    scan_head = strstart + 4 <= n ? uint32_t(win >> (8 * (wpos - 4 - strstart))) : word_at(strstart);
                     scan_end2 = pair_at(scan_head, strstart, best_len - 1);
                 } else decide = true;
             }
@@ -609,7 +656,7 @@ template <class In> struct Deflater {
                     if (bflush) { full = true; flush_at = next_start; }
                     ++strstart;
                 } else if (match_available) {
-                    const bool bflush = tally(0, byte_at(strstart - 1));
+                    const bool bflush = tally(0, win_byte(strstart - 1));
                     if (bflush) { full = true; flush_at = strstart; }
                     ++strstart;
                 } else {
@@ -625,6 +672,7 @@ template <class In> struct Deflater {
             flush_at = strstart;
         }
         s.last_lit = last_lit;
+        counts_settled();
         flush_block(block_start, flush_at - block_start, last);
         last_lit = 0;
         block_start = flush_at;
