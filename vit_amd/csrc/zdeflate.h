@@ -40,11 +40,10 @@ constexpr int kLCodes = 286, kDCodes = 30, kBLCodes = 19, kHeapSize = 2 * kLCode
 constexpr int kEndBlock = 256, kRep3_6 = 16, kRepz3_10 = 17, kRepz11_138 = 18, kMaxBits = 15, kMaxBLBits = 7;
 // level 6: good_length 8, max_lazy 16, nice_length 128, max_chain 128
 constexpr int kGood = 8, kLazy = 16, kNice = 128, kChain = 128;
-// Units of work a lane does in one turn of the scan's loop (see run): up to this many candidates of a hash chain, or up to
-// this many positions inside a match that has been emitted.  One of each keeps the lanes of a GPU wave busiest; a few
-// cost little waiting and spare the other parts of the loop body some of their turns (measured: 4 and 4, +9 % on
-// text-like objects over 1 and 1; 16 candidates -13 %, a whole chain of 128 -51 %).
-constexpr int kPerTurn = 4, kSkipPerTurn = 4;
+// Candidates of a hash chain a lane looks at in one turn of the scan's loop (see run).  One keeps the lanes of a GPU wave
+// busiest; a few cost little waiting and spare the other parts of the loop body some of their turns (measured on
+// text-like objects: 4 +9 % over 1; 16 -13 %; a whole chain of 128, as zlib nests it, -51 %).
+constexpr int kPerTurn = 4;
 
 // Constant tables (trees.c: tr_static_init), built once on the host by make_tables().
 struct Tables {
@@ -512,23 +511,53 @@ template <class In> struct Deflater {
         uint32_t ins_h = 0;
         if (n >= 2) ins_h = ((byte_at(0) << kHashShift) ^ byte_at(1)) & kHashMask;
 
-        // The bytes around the scan's position, in a register: input bytes [wpos - 8, wpos), the last in the lowest byte,
-        // topped up four at a time from whole words of the input.  The hash wants the byte two ahead of every position, a
-        // literal the byte one behind, a search the four from the position on: one load in four positions instead of
-        // one to three at each, and none of them in the way of what depends on them.
-        uint64_t win = 0;
+        // The bytes around the scan's position, in registers: input bytes [wpos - 16, wpos), the last in the lowest byte,
+        // topped up from whole words of the input.  The hash wants the byte two ahead of every position, a literal the
+        // byte one behind, a search the four from the position on.
+        unsigned __int128 win = 0;
         uint32_t wpos = 0;
-        auto top_up = [&](uint32_t upto) {                              // bytes below `upto` (<= n + 3) are in the window after this
+        const uint32_t win_cap = (n + 6u) & ~3u;                        // nothing from byte n + 3 on is ever wanted
+        auto top_up = [&](uint32_t upto) {                              // bytes below min(upto, win_cap) are in the window after this
+            if (upto > win_cap) upto = win_cap;
             while (wpos < upto) { win = (win << 32) | input.be32a(wpos); wpos += 4; }
         };
-        auto win_byte = [&](uint32_t j) -> uint32_t { return uint32_t(win >> (8 * (wpos - 1 - j))) & 0xffu; };   // wpos - 8 <= j < wpos
+        auto win_byte = [&](uint32_t j) -> uint32_t { return uint32_t(win >> (8 * (wpos - 1 - j))) & 0xffu; };   // wpos - 16 <= j < wpos
 
-        auto insert = [&](uint32_t str) -> uint32_t {                   // INSERT_STRING; returns the previous head
-            ins_h = ((ins_h << kHashShift) ^ win_byte(str + 2)) & kHashMask;
-            const uint32_t h = head[int(ins_h)];
-            prev[int(str & kWMask)] = uint16_t(h);
-            head[int(ins_h)] = uint16_t(str);
-            return h;
+        // INSERT_STRING for kAhead positions at a time, ahead of the scan.  Which positions enter the hash chains, and in
+        // which order, does not depend on the matches chosen (deflate_slow inserts every position that has three bytes
+        // left), and a position's chain only ever leads to earlier ones, so the positions [ins_upto, ins_upto + kAhead)
+        // are inserted together when the scan reaches the first of them: their hashes from the window, their kAhead
+        // heads loaded at once (each a cache miss of its own in a table of 64 KiB per object: together they cost one
+        // miss's wait instead of kAhead), positions of the same batch with the same hash chained among themselves, and
+        // every position's previous head kept for when the scan gets there.
+        constexpr int kAhead = 8;
+        uint32_t ins_upto = 0;
+        uint64_t heads_lo = 0, heads_hi = 0;                            // previous heads of the batch's positions, 16 bits each
+        auto insert_batch = [&]() {
+            const uint32_t b = ins_upto;
+            top_up(b + uint32_t(kAhead) + 4);
+            const uint32_t cnt = n >= b + 3u ? (n - 2u - b < uint32_t(kAhead) ? n - 2u - b : uint32_t(kAhead)) : 0u;
+            uint32_t h[kAhead], v[kAhead];
+            for (int j = 0; j < kAhead; ++j) {
+                h[j] = 0; v[j] = 0;
+                if (uint32_t(j) < cnt) { ins_h = ((ins_h << kHashShift) ^ win_byte(b + uint32_t(j) + 2)) & kHashMask; h[j] = ins_h; }
+            }
+            for (int j = 0; j < kAhead; ++j) if (uint32_t(j) < cnt) v[j] = head[int(h[j])];
+            heads_lo = 0; heads_hi = 0;
+            for (int j = 0; j < kAhead; ++j) {
+                if (uint32_t(j) < cnt) {
+                    uint32_t x = v[j];
+                    for (int i = 0; i < j; ++i) if (h[i] == h[j]) x = b + uint32_t(i);
+                    prev[int((b + uint32_t(j)) & kWMask)] = uint16_t(x);
+                    head[int(h[j])] = uint16_t(b + uint32_t(j));
+                    if (j < 4) heads_lo |= uint64_t(x) << (16 * j); else heads_hi |= uint64_t(x) << (16 * (j - 4));
+                }
+            }
+            ins_upto = b + uint32_t(kAhead);
+        };
+        auto head_before = [&](uint32_t str) -> uint32_t {              // the head that INSERT_STRING(str) found; str in the last batch
+            const uint32_t j = str - (ins_upto - uint32_t(kAhead));
+            return uint32_t((j < 4 ? heads_lo >> (16 * j) : heads_hi >> (16 * (j - 4))) & 0xffffu);
         };
         auto tally = [&](uint32_t dist, uint32_t lc) -> bool {          // _tr_tally
             d_buf[int(last_lit)] = uint16_t(dist);
@@ -568,7 +597,6 @@ template <class In> struct Deflater {
         // zlib flushes a block from inside the scan when the symbol buffer is full.  Here the scan stops instead, the one
         // flush below is done and the scan is entered again where it stopped: the block code is large, and in line at
         // every place that may flush it is three times the rest of the kernel.
-        uint32_t skip = 0;                                               // positions still to insert of a match already emitted
         bool searching = false;
         uint32_t cur = 0, chain = 0, limit = 0, best_len = 0, nice = 0;  // longest_match's state
         uint32_t scan_head = 0, scan_end2 = 0;                           // bytes 0..3 at strstart; bytes best_len-1, best_len
@@ -579,18 +607,11 @@ template <class In> struct Deflater {
             bool decide = false;
             lookahead = n - strstart;
             if (!searching) {
-                uint32_t hash_head = 0;
-                top_up(strstart + 4);
-                if (lookahead >= uint32_t(kMinMatch)) hash_head = insert(strstart);
-                if (skip != 0) {
-                    --skip; ++strstart;
-                    for (int rep = 1; rep < kSkipPerTurn && skip != 0; ++rep) {
-                        top_up(strstart + 4);
-                        if (n - strstart >= uint32_t(kMinMatch)) insert(strstart);
-                        --skip; ++strstart;
-                    }
-                    continue;
+                if (strstart >= ins_upto) {                  // after a long match: one batch a turn until the scan's position is in
+                    insert_batch();
+                    if (strstart >= ins_upto) continue;
                 }
+                const uint32_t hash_head = lookahead >= uint32_t(kMinMatch) ? head_before(strstart) : 0u;
                 prev_length = match_length; prev_match = match_start;
                 match_length = kMinMatch - 1;
                 if (hash_head != 0 && prev_length < uint32_t(kLazy) && strstart - hash_head <= uint32_t(kMaxDist)) {
@@ -646,15 +667,14 @@ template <class In> struct Deflater {
             }
             if (decide) {
                 if (prev_length >= uint32_t(kMinMatch) && match_length <= prev_length) {
-                    // the match found at the position before stands: its remaining positions are inserted by the turns
-                    // that follow (zlib inserts them here and flushes after them; the flush reads neither table)
+                    // the match found at the position before stands; its remaining positions are passed over (the batches
+                    // insert them; zlib inserts them here and flushes after them: the flush reads neither table)
                     const bool bflush = tally(strstart - 1 - prev_match, prev_length - kMinMatch);
-                    skip = prev_length - 2;
                     const uint32_t next_start = strstart + prev_length - 1;
                     match_available = false;
                     match_length = kMinMatch - 1;
                     if (bflush) { full = true; flush_at = next_start; }
-                    ++strstart;
+                    strstart = next_start;
                 } else if (match_available) {
                     const bool bflush = tally(0, win_byte(strstart - 1));
                     if (bflush) { full = true; flush_at = strstart; }
