@@ -268,9 +268,8 @@ class Hasher:
         self.sync(batch["dev"])
         return batch["digests"].download(np.uint8, 20 * batch["n"]).reshape(-1, 20)
 
-    def deflate_device_launch(self, batch, framed_lens, order=None, stream=None):
-        """Queue vit_deflate_arena_device for a batch from synth_arena() on `stream` (a hipStream_t as an integer;
-        None = the queue's own) and return what deflate_device_collect needs; nothing is waited for."""
+    def _deflate_device_prepare(self, batch, framed_lens):
+        """Output buffer, offsets and lengths in device memory for a vit_deflate_arena_device call."""
         n = batch["n"]
         lib = self.lib
         cap = np.array([max(lib.vit_deflate_bound(int(L)), 16) for L in framed_lens], dtype=np.uint64)
@@ -279,11 +278,18 @@ class Hasher:
         d_out = self.alloc(int(off[-1]) + 16, batch["dev"])
         d_off = self.alloc(8 * n, batch["dev"]).upload(off[:n].copy())
         d_len = self.alloc(4 * n, batch["dev"])
-        self._check(lib.vit_deflate_arena_device(self.handle, batch["dev"], batch["arena"].ptr, batch["arena_bytes"],
-                                                 batch["offsets"].ptr, batch["nblocks"].ptr,
-                                                 order.ptr if order is not None else None, n, d_out.ptr, d_off.ptr,
-                                                 d_len.ptr, C.c_void_p(stream) if stream else None))
-        return {"n": n, "off": off, "d_out": d_out, "d_off": d_off, "d_len": d_len, "order": order}
+        return {"n": n, "off": off, "d_out": d_out, "d_off": d_off, "d_len": d_len}
+
+    def deflate_device_launch(self, batch, framed_lens, order=None, stream=None, prepared=None):
+        """Queue vit_deflate_arena_device for a batch from synth_arena() on `stream` (a hipStream_t as an integer;
+        None = the queue's own) and return what deflate_device_collect needs; nothing is waited for."""
+        p = prepared if prepared is not None else self._deflate_device_prepare(batch, framed_lens)
+        self._check(self.lib.vit_deflate_arena_device(self.handle, batch["dev"], batch["arena"].ptr, batch["arena_bytes"],
+                                                      batch["offsets"].ptr, batch["nblocks"].ptr,
+                                                      order.ptr if order is not None else None, p["n"], p["d_out"].ptr,
+                                                      p["d_off"].ptr, p["d_len"].ptr, C.c_void_p(stream) if stream else None))
+        p["order"] = order
+        return p
 
     @staticmethod
     def deflate_device_collect(launched):
@@ -297,9 +303,10 @@ class Hasher:
         """zlib streams of a batch from synth_arena() (vit_deflate_arena_device).  framed_lens: header + content
         length per object (sizes the output).  Returns (list of bytes, seconds on the device)."""
         import time
+        prepared = self._deflate_device_prepare(batch, framed_lens)
         self.sync(batch["dev"])
         t0 = time.perf_counter()
-        launched = self.deflate_device_launch(batch, framed_lens, order)
+        launched = self.deflate_device_launch(batch, framed_lens, order, prepared=prepared)
         self.sync(batch["dev"])
         dt = time.perf_counter() - t0
         return self.deflate_device_collect(launched), dt
