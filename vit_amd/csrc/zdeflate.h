@@ -416,30 +416,41 @@ template <class In> struct Deflater {
         return max_blindex;
     }
 
-    ZD_FN unsigned d_code(unsigned dist) const { return dist < 256 ? s.t->dist_code[dist] : s.t->dist_code[256 + (dist >> 7)]; }
 
+    // compress_block: the block's symbols in their codes.  Four symbols at a time: their two buffer entries are loaded
+    // together, then the codes of the literals among them, and only then are bits sent, so a lane waits for two memory
+    // round trips in four symbols instead of two in each.  A match's extra bits and their count are worked out from its
+    // codes (trees.c looks them up in extra_lbits, base_length, extra_dbits and base_dist): from code 8 on a length code
+    // has (code >> 2) - 1 extra bits and they are the low bits of length - 3, from code 4 on a distance code has
+    // (code >> 1) - 1 and they are the low bits of distance - 1; length code 28 (258) has none.
     ZD_FN void compress_block(bool fixed)
     {
         uint32_t lx = 0;
-        if (s.last_lit != 0) do {
-            unsigned dist = s.w.d_buf[int(lx)];
-            unsigned lc = s.w.l_buf[int(lx)];
-            lx++;
-            if (dist == 0) {
-                if (fixed) send_bits(s.t->static_lcode[lc], s.t->static_llen[lc]); else send_bits(s.lt_fc[lc], s.lt_dl[lc]);
-            } else {
-                unsigned code = s.t->length_code[lc];
-                const unsigned sym = code + kLiterals + 1;
-                if (fixed) send_bits(s.t->static_lcode[sym], s.t->static_llen[sym]); else send_bits(s.lt_fc[sym], s.lt_dl[sym]);
-                int extra = s.t->extra_lbits[code];
-                if (extra != 0) { lc -= s.t->base_length[code]; send_bits(lc, extra); }
-                dist--;
-                code = d_code(dist);
-                if (fixed) send_bits(s.t->static_dcode[code], 5); else send_bits(s.dt_fc[code], s.dt_dl[code]);
-                extra = s.t->extra_dbits[code];
-                if (extra != 0) { dist -= s.t->base_dist[code]; send_bits(dist, extra); }
+        while (lx < s.last_lit) {
+            const uint32_t g = s.last_lit - lx < 4u ? s.last_lit - lx : 4u;
+            unsigned dist[4], lc[4], code[4], bits[4];
+            for (uint32_t k = 0; k < 4; ++k) {
+                dist[k] = 0; lc[k] = 0; code[k] = 0; bits[k] = 0;
+                if (k < g) { dist[k] = s.w.d_buf[int(lx + k)]; lc[k] = s.w.l_buf[int(lx + k)]; }
             }
-        } while (lx < s.last_lit);
+            for (uint32_t k = 0; k < 4; ++k)
+                if (k < g && dist[k] == 0) {
+                    code[k] = fixed ? s.t->static_lcode[lc[k]] : s.lt_fc[int(lc[k])];
+                    bits[k] = fixed ? s.t->static_llen[lc[k]] : s.lt_dl[int(lc[k])];
+                }
+            for (uint32_t k = 0; k < g; ++k) {
+                if (dist[k] == 0) { send_bits(code[k], int(bits[k])); continue; }
+                const unsigned lcode = length_code_of(lc[k]);
+                const unsigned sym = lcode + kLiterals + 1;
+                if (fixed) send_bits(s.t->static_lcode[sym], s.t->static_llen[sym]); else send_bits(s.lt_fc[int(sym)], s.lt_dl[int(sym)]);
+                if (lcode >= 8 && lcode < 28) { const int extra = int(lcode >> 2) - 1; send_bits(lc[k] & ((1u << extra) - 1u), extra); }
+                const unsigned d = dist[k] - 1;
+                const unsigned dcode = dist_code_of(d);
+                if (fixed) send_bits(s.t->static_dcode[dcode], 5); else send_bits(s.dt_fc[int(dcode)], s.dt_dl[int(dcode)]);
+                if (dcode >= 4) { const int extra = int(dcode >> 1) - 1; send_bits(d & ((1u << extra) - 1u), extra); }
+            }
+            lx += g;
+        }
         if (fixed) send_bits(s.t->static_lcode[kEndBlock], s.t->static_llen[kEndBlock]);
         else send_bits(s.lt_fc[kEndBlock], s.lt_dl[kEndBlock]);
     }
@@ -699,10 +710,14 @@ template <class In> struct Deflater {
         if (last) break;
         }
 
-        // adler32 of the input, big-endian
+        // adler32 of the input, big-endian; the input four bytes to a load
         uint32_t a = 1, b = 0;
         for (uint32_t i = 0; i < n;) {
-            const uint32_t end = i + 5552 < n ? i + 5552 : n;
+            const uint32_t end = i + 5552 < n ? i + 5552 : n;           // 5552 is a multiple of four: i stays one
+            for (; i + 4 <= end; i += 4) {
+                const uint32_t w = input.be32a(i);
+                a += w >> 24; b += a; a += (w >> 16) & 0xffu; b += a; a += (w >> 8) & 0xffu; b += a; a += w & 0xffu; b += a;
+            }
             for (; i < end; ++i) { a += input(i); b += a; }
             a %= 65521u; b %= 65521u;
         }
