@@ -94,3 +94,21 @@ def test_launches_on_two_streams_take_turns_with_the_queues_workspace(hasher):
     for k in range(2):
         assert hasher.deflate_device_collect(launched[k]) == alone[k], k
     assert hasher.device_status() == 0
+
+
+def test_text_like_objects_at_the_size_of_a_batch(hasher):
+    """8,192 text-like objects (words drawn with a Zipf law: a hash chain to walk at nearly every position, matches of every
+    length, lanes of a wave far apart in their objects) of 200 to 16,000 bytes: every stream is zlib's."""
+    rng = np.random.default_rng(77)
+    vocab = [bytes(rng.integers(97, 123, int(k)).astype(np.uint8)) for k in rng.integers(2, 10, 2000)]
+    vocab += [b"    ", b"\n", b"{", b"}", b"(", b")", b";", b"return ", b"const ", b"int ", b"if (", b"for ("]
+    pick = np.minimum(rng.zipf(1.3, 1_200_000), len(vocab)) - 1
+    text = b" ".join(vocab[int(k)] for k in pick)
+    n = 8192
+    lens = rng.integers(200, 16000, n)
+    starts = rng.integers(0, len(text) - 16000, n)
+    blobs = [text[int(s):int(s) + int(L)] for s, L in zip(starts, lens)]
+    got, _ = hasher.deflate_objects("blob", blobs)
+    for d, z in zip(blobs, got):
+        assert z == zlib.compress(_framed("blob", d), 6), len(d)
+    assert hasher.device_status() == 0
