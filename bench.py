@@ -332,8 +332,19 @@ def headline_write_tree(O, vit, files=1_000_000, cpu_files=50_000):
     return rec
 
 
+def claim_stdout():
+    """Exactly one line goes to stdout.  Libraries loaded below write to descriptor 1 on their own (RCCL prints a
+    version banner there when a process group forms): descriptor 1 points at stderr for the rest of the process,
+    and the returned descriptor is the real stdout, kept for the result line."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     args = parse()
+    result_fd = claim_stdout()
     import torch
     import vit_amd
     from vit_amd import dist as vdist
@@ -427,7 +438,8 @@ def main():
     vdist.release_ranks(dist)
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline(args, dig)
-    print(json.dumps(line), flush=True)
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

@@ -113,6 +113,7 @@ def test_bench_runs_as_two_ranks_on_one_gpu():
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout                   # rank 0 alone prints
+    assert out.stdout.strip().splitlines() == lines, out.stdout   # and nothing else reaches stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 5 and d["scaling"] == "weak" and d["device_status"] == 0
     assert abs(d["objects_per_s"] - 2 * 200000 * 5 / (d["ms_per_step"] * 5e-3)) / d["objects_per_s"] < 0.01
