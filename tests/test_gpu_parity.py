@@ -20,6 +20,20 @@ def assert_same(got, want, labels):
     assert len(bad) == 0, "digests differ at %s" % [labels[i] for i in bad[:12]]
 
 
+def tail_cases():
+    """A batch of short objects, which must not pay the software scheduler's price, and one with a long tail,
+    which must get its benefit (also used by tests/test_zzz_gpu_perf.py)."""
+    rng = np.random.default_rng(77)
+    return {"short": rng.integers(0, 257, 600_000).astype(np.uint64),
+            "tail": np.concatenate([rng.integers(0, 2000, 400_000), [3_000_000, 2_500_000]]).astype(np.uint64)}
+
+
+def skewed_sizes_beyond_4gib(n=340_000):
+    rng = np.random.default_rng(5)
+    sizes = np.exp(rng.normal(np.log(4500.0), 1.55, n))
+    return np.minimum(sizes * (15000.0 / sizes.mean()), 131072).astype(np.uint64)
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_golden_blob_ids_from_the_reference(hasher, oracle, golden_objects, kernel):
     g = golden_objects["blobs"]
@@ -239,14 +253,10 @@ def test_software_scheduled_launch_gives_the_same_ids(hasher, waves):
 def test_scheduled_launch_is_chosen_by_the_tail(hasher):
     """Default options, lengths known to the device only: the scheduled launch and the plain one are both
     queued and their waves decide (longest object against a SIMD's mean share of the work).  Same ids either
-    way; a batch of short objects must not pay the scheduler's price (it ran 3.3 times slower under it), a
-    batch with a long tail must get its benefit."""
-    import statistics
+    way, and from the entry point that allocates nothing too.  (What the choice costs in time is checked in
+    tests/test_zzz_gpu_perf.py, which runs last.)"""
     import vit_amd
-    rng = np.random.default_rng(77)
-    cases = {"short": rng.integers(0, 257, 600_000).astype(np.uint64),
-             "tail": np.concatenate([rng.integers(0, 2000, 400_000), [3_000_000, 2_500_000]]).astype(np.uint64)}
-    for name, lens in cases.items():
+    for name, lens in tail_cases().items():
         n = len(lens)
         b = hasher.synth_arena("blob", 0x5EED0090, 0, n, 0, lens=lens)
         nb = b["nblocks"].download(np.uint32, 4 * n)
@@ -254,22 +264,19 @@ def test_scheduled_launch_is_chosen_by_the_tail(hasher):
         order = hasher.alloc(4 * n).upload(order_host)
         hasher.set_option("sched_waves", 0)
         want = hasher.hash_device(b, order=order).copy()
-        t_plain = statistics.median(hasher.time_hash_device(b, order=order, warmup=1, iters=5))
         hasher.set_option("sched_waves", 1)
         hasher.set_option("sched_tail_percent", 0)
-        t_forced = statistics.median(hasher.time_hash_device(b, order=order, warmup=1, iters=5))
+        b["digests"].upload(np.zeros(20 * n, dtype=np.uint8))
+        assert (hasher.hash_device(b, order=order) == want).all(), name
         hasher.set_option("sched_tail_percent", 75)
         b["digests"].upload(np.zeros(20 * n, dtype=np.uint8))
         assert (hasher.hash_device(b, order=order) == want).all(), name
-        t_auto = statistics.median(hasher.time_hash_device(b, order=order, warmup=1, iters=5))
         b["digests"].upload(np.zeros(20 * n, dtype=np.uint8))
         assert (hasher.hash_device_static(b) == want).all(), name
         for i in (0, n - 1, int(np.argmax(lens))):
             data = vit_amd.synth_bytes(0x5EED0090, i, int(lens[i]))
             assert want[i].tobytes() == hashlib.sha1(b"blob %d\0" % len(data) + data).digest()
         assert hasher.device_status() == 0
-        # the choice lands on the faster launch, give or take the cost of the launch that steps aside
-        assert t_auto < 1.25 * min(t_plain, t_forced) + 0.03, (name, t_plain, t_forced, t_auto)
 
 
 def test_plain_sha1_of_buffers(hasher, oracle, golden_objects):
@@ -414,33 +421,24 @@ def test_waves_spanning_more_than_4gib_take_the_per_lane_path(hasher):
         assert far[i].tobytes() == want
 
 
-def test_binned_skewed_arena_beyond_4gib_keeps_its_rate(hasher):
-    """A coarse guard on speed, not a benchmark: a skewed batch in an arena beyond 4 GiB, hashed in binned
-    order (every wave's objects lie all over the arena), must stay within 2.2x of the time the same number
-    of blocks takes on uniform objects.  (Sending such waves to a plain per-lane loop once cost 2.6x.)"""
+def test_binned_skewed_arena_beyond_4gib_gives_the_right_ids(hasher):
+    """A skewed batch in an arena beyond 4 GiB, hashed in binned order: every wave's objects lie all over the
+    arena, so most waves address their objects with 64 bits per lane.  (Its speed is checked in
+    tests/test_zzz_gpu_perf.py, which runs last.)"""
     import vit_amd
-    n = 340_000
-    rng = np.random.default_rng(5)
-    sizes = np.exp(rng.normal(np.log(4500.0), 1.55, n))
-    sizes = np.minimum(sizes * (15000.0 / sizes.mean()), 131072).astype(np.uint64)
+    sizes = skewed_sizes_beyond_4gib()
+    n = len(sizes)
     b = hasher.synth_arena("blob", 0x5EED0044, 0, n, 0, lens=sizes)
     assert b["arena_bytes"] > (1 << 32)
     nb = b["nblocks"].download(np.uint32, 4 * n)
     order_host, differs = vit_amd.bin_order(nb)
     assert differs
     order = hasher.alloc(4 * n).upload(order_host)
-    skew_ms = min(hasher.time_hash_device(b, order=order, warmup=1, iters=3))
-    got = b["digests"].download(np.uint8, 20 * n).reshape(-1, 20)
-    for i in (0, 7, n - 1, int(np.argmax(sizes))):
+    got = hasher.hash_device(b, order=order)
+    assert hasher.device_status() == 0
+    for i in [0, 7, n - 1, int(np.argmax(sizes))] + np.random.default_rng(8).integers(0, n, 60).tolist():
         want = hashlib.sha1(b"blob %d\0" % int(sizes[i]) + vit_amd.synth_bytes(0x5EED0044, i, int(sizes[i]))).digest()
         assert got[i].tobytes() == want
-    del b
-    u = hasher.synth_arena("blob", 1, 0, 200_000, 4096)
-    uni_ms = min(hasher.time_hash_device(u, warmup=1, iters=3))
-    per_block = uni_ms / (200_000 * 65)
-    floor_ms = float(nb.astype(np.uint64).sum()) * per_block
-    print("skewed %.3f ms, floor %.3f ms, ratio %.2f" % (skew_ms, floor_ms, skew_ms / floor_ms))
-    assert skew_ms < 2.2 * floor_ms, (skew_ms, floor_ms)
 
 
 def test_config2_full_size_1m_x_4k(hasher):
