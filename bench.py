@@ -166,8 +166,13 @@ def mixed_leg(lib, ids, m, scaling):
         h.set_option("pack_threads", max(2, min(len(os.sched_getaffinity(0)), 16 * len(ids))))
         dig, (total_ns, pack_ns, on_gpu, on_host, bytes_host, h2d, plan_ns, gpu_done_ns, host_done_ns) = \
             time_host_batch(h, ptrs, sizes, m)
-        rates = {k: h.stat(k) for k in ("lane_rate", "core_rate", "core_rate_multi", "copy_rate", "pack_rate")}
+        rates = {k: h.stat(k) for k in ("lane_rate", "core_rate", "core_rate_multi", "copy_rate", "copy_rate_total", "pack_rate")}
         threads = h.stat("pool_threads") + (len(ids) if len(ids) > 1 else 1)
+        node = lambda v: None if v == 2 ** 64 - 1 else v
+        placement = {"queue_numa_node": [node(h.stat("queue_numa_node:%d" % k)) for k in range(len(ids))],
+                     "staging_arena_numa_node": [node(h.stat("arena_numa_node:%d" % k)) for k in range(len(ids))],
+                     "workers_pinned": h.stat("workers_pinned"), "host_bias_percent": h.stat("host_bias_percent"),
+                     "cpus_allowed": len(os.sched_getaffinity(0))}
     mv = memoryview(buf)
     ok = True
     for i in [0, m - 1, int(np.argmax(sizes))] + np.random.default_rng(3).integers(0, m, 200).tolist():
@@ -183,8 +188,10 @@ def mixed_leg(lib, ids, m, scaling):
         "gpu_side_GBps": round((payload - bytes_host) / max(gpu_done_ns, 1), 2),
         "host_side_GBps": round(bytes_host / max(host_done_ns, 1), 2),
         "objects_gpu": on_gpu, "objects_host": on_host, "bytes_host": bytes_host, "bytes_h2d": h2d,
-        "host_threads": threads, "measured_rates_bytes_per_s": rates,
-        "bound": "GPU side: %d x PCIe (%.0f GB/s spec each) or the host's DRAM/packing threads, whichever is lower; "
+        "host_threads": threads, "measured_rates_bytes_per_s": rates, "copy_rate_total": rates["copy_rate_total"],
+        "placement": placement,
+        "bound": "GPU side: %d x PCIe (%.0f GB/s spec each), what the queues get when they all copy at once (copy_rate_total, "
+                 "measured) or the host's DRAM/packing threads, whichever is lower; "
                  "host side: %d threads x the measured core rate (core_rate_multi where objects outnumber threads: four SHA-1 "
                  "streams interleaved per core); the two sides run concurrently and add up"
                  % (len(ids), PCIE_GBS, threads),
@@ -195,14 +202,24 @@ def mixed_leg(lib, ids, m, scaling):
 
 
 # --------------------------------------------------------------- CPU baseline --
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, gpu_digests_of_sample):
     """The reference's hashing loop (src/commit.cpp:90-94) and its whole write-tree (:139-173, :98-111) on
     host cores, on bounded samples.  Checker/measurement only."""
     from oracle import pyoracle as O
     n_sample = min(args.blobs, 65536)
-    cores = os.cpu_count() or 1
-    cores = min(cores, 16) if os.environ.get("OMP_NUM_THREADS") is None else min(cores, int(os.environ["OMP_NUM_THREADS"]))
-    blobs = O.synth_fill_many(SEED, 0, n_sample, args.blob_len, threads=cores)
+    allowed = len(os.sched_getaffinity(0))
+    cores = min(allowed, int(os.environ["OMP_NUM_THREADS"])) if os.environ.get("OMP_NUM_THREADS") else allowed
+    blobs = O.synth_fill_many(SEED, 0, n_sample, args.blob_len, threads=min(cores, 64))
     offsets = (np.arange(n_sample, dtype=np.uint64) * np.uint64(args.blob_len))
     lens = np.full(n_sample, args.blob_len, dtype=np.uint64)
     # calibrate, then repeat the sample until ~cpu_seconds/2 of single-thread work is done
@@ -213,13 +230,23 @@ def cpu_baseline(args, gpu_digests_of_sample):
         s, dig, used = O.bench_hash_loop(blobs, offsets, lens, threads=1)
         t1.append(s)
     sec1 = statistics.median(t1)
-    tn = []
-    for _ in range(max(3, int((args.cpu_seconds * 0.3) / max(sec / cores, 1e-6)) // 4)):
-        s, dign, _ = O.bench_hash_loop(blobs, offsets, lens, threads=cores)
-        tn.append(s)
-    secn = statistics.median(tn)
     parity = bool((dig == gpu_digests_of_sample[:n_sample]).all())
     payload = n_sample * args.blob_len
+    # All cores: threads that exist before the clock starts and are released together, enough passes over the
+    # sample for at least 1 GB and about a tenth of the CPU budget of wall time per run, median of 3.
+    def all_cores(per_thread_ctx):
+        passes = max(-(-(1 << 30) // payload), 1)
+        s, d, how = O.bench_hash_loop_mt(blobs, offsets, lens, cores, reps=passes, per_thread_ctx=per_thread_ctx)
+        passes = max(passes, int(passes * (args.cpu_seconds * 0.1) / max(s, 1e-6)))
+        runs = []
+        for _ in range(3):
+            s, d, how = O.bench_hash_loop_mt(blobs, offsets, lens, cores, reps=passes, per_thread_ctx=per_thread_ctx)
+            runs.append(s)
+        s = statistics.median(runs)
+        return {"value": round(passes * payload / s / 1e9, 4), "unit": "GB/s", "cores": cores,
+                "objects_per_s": round(passes * n_sample / s, 1), "bytes_hashed_per_run": passes * payload,
+                "seconds_per_run": round(s, 4), "matches_one_core": bool((d == dig).all()),
+                "sha1": {0: "oracle SHA-1", 1: "libcrypto SHA1() per object", 2: "libcrypto EVP, one context per thread"}[how]}
     out = {
         "value": round(payload / sec1 / 1e9, 4), "unit": "GB/s", "cores": 1,
         "kind": "port",
@@ -227,8 +254,15 @@ def cpu_baseline(args, gpu_digests_of_sample):
                   "src/commit.cpp:90-94, median of %d runs" % (n_sample, args.blob_len, payload / 1e6,
                                                               "libcrypto SHA1()" if used else "oracle SHA-1", reps),
         "objects_per_s": round(n_sample / sec1, 1),
-        "all_cores": {"value": round(payload / secn / 1e9, 4), "unit": "GB/s", "cores": cores,
-                      "objects_per_s": round(n_sample / secn, 1)},
+        "host": {"cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "cpus_this_process_may_use": allowed,
+                 "threads_used_for_all_cores": cores},
+        "all_cores": all_cores(False),
+        "all_cores_one_context_per_thread": all_cores(True),
+        "all_cores_note": "all_cores is the reference's loop as written, sharded over threads that are started before the clock and "
+                          "released together. It does not scale as its arithmetic would: OpenSSL 3's one-shot SHA1() looks the "
+                          "algorithm up on every call (EVP_MD_fetch) under a lock the threads contend for. The second figure is "
+                          "the same loop with the lookup done once and one digest context per thread, i.e. what the host's cores "
+                          "give a multi-threaded port of the reference; the reference itself is single-threaded (value).",
         "gpu_matches_cpu_on_sample": parity,
     }
     out["write_tree"] = cpu_write_tree(O)
@@ -333,6 +367,36 @@ def headline_write_tree(O, vit, files=1_000_000, cpu_files=50_000):
     return rec
 
 
+def kernel_source_sha256():
+    """What the SHA-1 kernels are compiled from: a counter record taken from other sources is about another kernel."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "sha1_device.h", "kernels.h"):
+        h.update(open(os.path.join(HERE, "vit_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
+def hbm_traffic_record(kernel_name, n, blob_len):
+    """HBM bytes per launch from the tracked counter record (profiles/hbm_traffic.json, written by
+    tools/summarize_profile.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command), and where it comes
+    from.  The record is used only if it is about the kernel timed here: same kernel name, same kernel sources, same
+    workload; otherwise traffic is null and the reason is given."""
+    tpath = os.path.join(HERE, "profiles", "hbm_traffic.json")
+    try:
+        rec = json.load(open(tpath))
+    except Exception as e:
+        return None, "no usable profiles/hbm_traffic.json (%s)" % type(e).__name__
+    if kernel_name not in rec.get("kernel", ""):
+        return None, "profiles/hbm_traffic.json is about %r, not %r: not reported" % (rec.get("kernel"), kernel_name)
+    if rec.get("kernel_source_sha256") != kernel_source_sha256():
+        return None, "profiles/hbm_traffic.json was collected from other kernel sources (%s...): not reported" \
+            % str(rec.get("kernel_source_sha256"))[:12]
+    if rec.get("objects_per_launch") != n or rec.get("object_bytes") != blob_len:
+        return None, "profiles/hbm_traffic.json is about %s x %s B: not reported" % (rec.get("objects_per_launch"), rec.get("object_bytes"))
+    return rec.get("bytes_per_launch"), {"file": "profiles/hbm_traffic.json", "summary": rec.get("summary"),
+                                         "collected_at_commit": rec.get("commit"), "kernel_source_sha256": rec.get("kernel_source_sha256")}
+
+
 def claim_stdout():
     """Exactly one line goes to stdout.  Libraries loaded below write to descriptor 1 on their own (RCCL prints a
     version banner there when a process group forms): descriptor 1 points at stderr for the rest of the process,
@@ -404,13 +468,8 @@ def main():
     alg_bytes = n * (hdr + L + 20)                                # per launch: framed message read + digest written
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     valu_tops = n * nb * OPS_PER_BLOCK / (kern_ms * 1e-3) / 1e12
-    traffic = None
-    tpath = os.path.join(HERE, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("bytes_per_launch")
-        except Exception:
-            traffic = None
+    kernel_name = "sha1_lds_kernel<2, 4>" if args.kernel == "lds" else "sha1_lane_kernel"
+    traffic, traffic_source = hbm_traffic_record(kernel_name, n, L)
 
     dig = batch["digests"].download(np.uint8, 20 * n).reshape(-1, 20)
     line = {
@@ -425,18 +484,20 @@ def main():
                                % (n, L),
                    "blobs_per_gpu": n, "blob_bytes": L, "blocks_per_blob": nb, "kernel": args.kernel,
                    "parallelism": "file-sharded x%d, no collective" % world},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                     "kernel": "sha1_lds_kernel<2, 4>" if args.kernel == "lds" else "sha1_lane_kernel",
-                     "kernel_ms_avg": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                     "note": "the kernel is bound by integer VALU issue, not HBM: see valu",
-                     "valu": {"achieved": round(valu_tops, 2), "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
-                              "frac": round(valu_tops / VALU_PEAK_TOPS, 4), "ops_per_block": OPS_PER_BLOCK,
-                              "peak_definition": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: the issue rate measured on this "
-                                                 "chip for 3-source-operand and shift/rotate instructions (533 of the 597 per "
-                                                 "block; tools/valu_ubench.hip, profiles/r02_valu_ubench.txt). 2-source "
-                                                 "add/xor alone issue at ~2x that but not in this mix (measured 4.0 "
-                                                 "cycles/instruction over the whole SHA-1 stream)"}},
+        "roofline": {"bound": "valu", "achieved": round(valu_tops, 2), "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
+                     "frac": round(valu_tops / VALU_PEAK_TOPS, 4), "ops_per_block": OPS_PER_BLOCK,
+                     "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel": kernel_name, "kernel_ms_avg": round(kern_ms, 4),
+                     "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_ops_per_launch": n * nb * OPS_PER_BLOCK,
+                     "peak_definition": "256 CU x 4 SIMD x 16 lanes/clk x 2.4 GHz: the issue rate measured on this "
+                                        "chip for 3-source-operand and shift/rotate instructions (533 of the 597 per "
+                                        "block; tools/valu_ubench.hip, profiles/r02_valu_ubench.txt). 2-source "
+                                        "add/xor alone issue at ~2x that but not in this mix (measured 4.0 "
+                                        "cycles/instruction over the whole SHA-1 stream)",
+                     "note": "integer VALU issue binds this kernel (no dense contraction, so no MFMA line); the HBM line is "
+                             "given beside it: at the VALU ceiling the kernel needs about half of HBM peak",
+                     "hbm": {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(achieved / HBM_PEAK_GBS, 4)}},
         "device_status": status,
     }
     batch = None

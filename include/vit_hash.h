@@ -122,16 +122,22 @@ int vit_hasher_device_count(const vit_hasher *h);
  *                         and their waves decide: those of the one not chosen leave at once
  *  "sched_share_below"    a spare wave works only while its SIMD's leader is on a group of at
  *                         most this many blocks (default 128)
- *  "debug_fail_at_chunk"  tests only: the N-th staged chunk of every later call fails
- *                         as if a HIP call had (0 = off)
- *  "trace"                1: vit_hash_objects prints one line per staged
- *                         chunk to stderr (host and device timestamps of
- *                         pack, copy, kernel and read-back)
- *  "wave_trace_ptr"       diagnostics: a device address with room for 32 bytes
- *                         per wave (4 waves per 256 objects); while it is set,
- *                         every wave of a launch records there when it started
- *                         and ended (100 MHz clock), its hardware id (SIMD, CU,
- *                         SE, XCD) and its longest object in blocks; 0 = off */
+ *  "copy_rate_total"      what ALL device queues of the hasher get out of pinned host-to-device
+ *                         copies when they copy at once, bytes per second: with one queue the
+ *                         same as "copy_rate"; with several it is measured by one copy on every
+ *                         queue at the same time, and is what the balance divides the GPU side's
+ *                         bytes by when it is less than the queues' own rates added up (queues
+ *                         that share a PCIe link, a socket's root complex or the host's DRAM do
+ *                         not each get what one of them gets alone); setting fixes, 0 measures
+ *  "numa_pin"             1 (default): the pool's workers are pinned, in proportion to the queues
+ *                         there, to the CPUs of the NUMA nodes the GPUs hang off, and a queue's
+ *                         packing goes to the workers of its node first (its pinned staging arena
+ *                         lies in that node's memory); nothing is pinned where a GPU's node is
+ *                         unknown or a node has fewer usable CPUs than workers it would get.
+ *                         0: workers run where the scheduler puts them
+ *  "deflate_max_bytes" "deflate_lanes"   see vit_deflate_objects, vit_deflate_arena_device
+ * Options for tests and diagnostics ("debug_*", "trace", "wave_trace_ptr") are
+ * listed in vit_hash_bench.h. */
 int vit_hasher_set_option(vit_hasher *h, const char *name, uint64_t value);
 
 /* Counters since creation: "objects_gpu", "objects_host", "bytes_host",
@@ -141,8 +147,12 @@ int vit_hasher_set_option(vit_hasher *h, const char *name, uint64_t value);
  * last host-lane task of the last call had finished, from its start), "last_host_threshold" (shortest length moved to
  * the host threads, less one), "last_host_objects"; "host_bias_percent"; the four rates above and
  * "calibrate_ns" (what measuring them cost); "pool_threads", "pool_peak_busy"
- * (most pool threads inside a task at once); and "host_sha_accelerated" (1 when
- * the host lane uses the CPU's SHA extensions). */
+ * (most pool threads inside a task at once); "host_sha_accelerated" (1 when
+ * the host lane uses the CPU's SHA extensions); "copy_rate_total";
+ * "workers_pinned" (pool workers pinned to a NUMA node); and per device queue k,
+ * "queue_numa_node:k" (node of the GPU's PCIe function) and "arena_numa_node:k"
+ * (node the first page of the queue's pinned staging arena lies on), each
+ * 2^64 - 1 when unknown. */
 int vit_hasher_get_stat(const vit_hasher *h, const char *name, uint64_t *value);
 
 /* ---- framing (reference src/commit.cpp:90) ------------------------------- */
@@ -287,25 +297,6 @@ uint32_t vit_deflate_bound(uint64_t framed_len);
  * reference is single-threaded and has no counterpart (src/commit.cpp:143). */
 int vit_shard_plan(const uint32_t *nblocks, uint64_t n, int n_queues, uint32_t *queue_of);
 
-/* The balance "host_auto" strikes, as a plan: on_host[i] = 1 if object i (content
- * length len[i]) would be hashed on host threads beside the GPU batch, given
- * bytes-per-second rates of one GPU lane, one host core hashing, one pinned
- * host-to-device copy and one host core packing, the number of device queues and
- * the host thread budget.  Objects under 16 KiB never move; from the longest
- * down, objects move while the host side (hashing what moved plus packing what
- * stayed, over the threads) would still finish before the GPU side (its bytes
- * through 0.8 x copy rate per queue, never less than its longest object on one
- * lane); a run of equal lengths may be split.  Host-only; needs no device.  The
- * reference hashes every object on its one thread (src/commit.cpp:93-94). */
-int vit_host_split_plan(const uint64_t *len, uint64_t n, uint64_t lane_rate, uint64_t core_rate,
-                        uint64_t copy_rate, uint64_t pack_rate, int n_queues, int threads,
-                        uint8_t *on_host);
-
-/* Launch shape of the SHA-1 kernel for n objects (n <= 2^32 - 1): workgroups
- * and threads per workgroup.  Host-only; lets the launch arithmetic be checked
- * at sizes no test can allocate. */
-int vit_launch_shape(int kernel, uint64_t n, uint32_t *blocks, uint32_t *threads);
-
 /* Hash a packed arena that lives in host memory on device queue `dev`
  * (0 <= dev < vit_hasher_device_count).  Offsets and block counts are checked
  * against arena_bytes on the host before anything is launched.  An arena whose
@@ -353,41 +344,6 @@ int vit_hash_arena_device_static(vit_hasher *h, int dev, const void *d_arena, ui
  * 1 out of bounds, 2 misaligned offset, 4 bad order entry).  No other stream of
  * the device is stalled. */
 int vit_device_status(vit_hasher *h, int dev, uint32_t *status);
-
-/* ---- device memory, for callers without a HIP binding of their own -------- */
-int vit_device_alloc(vit_hasher *h, int dev, uint64_t bytes, void **out);
-int vit_device_free(vit_hasher *h, int dev, void *p);
-int vit_device_upload(vit_hasher *h, int dev, void *d_dst, const void *src, uint64_t bytes);
-int vit_device_download(vit_hasher *h, int dev, void *dst, const void *d_src, uint64_t bytes);
-int vit_device_sync(vit_hasher *h, int dev);
-
-/* ---- synthetic inputs and measurement ------------------------------------ */
-
-/* Fill a device arena with n framed, padded objects whose content is the
- * counter-based splitmix64 stream (seed, first_index + i).  d_lens == NULL:
- * every object has len_each bytes, and d_offsets/d_nblocks are outputs;
- * otherwise d_lens and d_offsets are inputs and d_nblocks is an output.
- * The reference ships no benchmark inputs; this generator is this library's. */
-int vit_synth_arena_device(vit_hasher *h, int dev, const char *type, uint64_t seed,
-                           uint64_t first_index, uint64_t n, uint64_t len_each,
-                           const uint64_t *d_lens, uint64_t *d_offsets, uint32_t *d_nblocks,
-                           void *d_arena, uint64_t arena_bytes, void *stream);
-/* Host restatement of the same byte stream (for checking the generator). */
-void vit_synth_bytes(uint64_t seed, uint64_t index, uint8_t *dst, uint64_t len);
-
-/* Launch the device-resident hash `iters` times after `warmup` untimed
- * launches and report each launch's duration in milliseconds, measured with
- * HIP events on the launch stream. */
-int vit_time_hash_device(vit_hasher *h, int dev, const void *d_arena, uint64_t arena_bytes,
-                         const uint64_t *d_offsets, const uint32_t *d_nblocks,
-                         const uint32_t *d_order, uint64_t n, uint8_t *d_digests,
-                         int warmup, int iters, float *ms_each);
-
-/* Compute-only ceiling of the SHA-1 instruction stream on this device: n_lanes
- * lanes each run blocks_per_lane compressions on register data.  *ms = one
- * launch (best of iters). */
-int vit_valu_peak(vit_hasher *h, int dev, uint32_t n_lanes, uint32_t blocks_per_lane,
-                  int iters, float *ms);
 
 #ifdef __cplusplus
 }

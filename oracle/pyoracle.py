@@ -55,6 +55,10 @@ def lib():
                                                  C.c_uint64, C.c_int, C.c_int, C.c_void_p,
                                                  C.POINTER(C.c_int)]
         L.vit_oracle_bench_hash_loop.restype = C.c_double
+        L.vit_oracle_bench_hash_loop_mt.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                    C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                                    C.POINTER(C.c_int)]
+        L.vit_oracle_bench_hash_loop_mt.restype = C.c_double
         _LIB = L
     return _LIB
 
@@ -229,6 +233,22 @@ def bench_hash_loop(blobs, offsets, lens, threads=1, want_libcrypto=True, type_=
                                            lens.ctypes.data, n, threads, int(want_libcrypto),
                                            dig.ctypes.data, C.byref(used))
     return sec, dig, bool(used.value)
+
+
+def bench_hash_loop_mt(blobs, offsets, lens, threads, reps=1, per_thread_ctx=False, want_libcrypto=True, type_="blob"):
+    """The same loop on `threads` threads that exist before the clock starts (released together, stopped together),
+    `reps` passes over the sample.  per_thread_ctx: one libcrypto digest context per thread instead of the one-shot
+    SHA1() per object.  Returns (seconds for all passes, digests[n,20], 0 oracle SHA-1 / 1 SHA1() / 2 per-thread EVP)."""
+    blobs = np.ascontiguousarray(blobs, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint64)
+    n = len(lens)
+    dig = np.zeros((n, 20), dtype=np.uint8)
+    used = C.c_int(0)
+    sec = lib().vit_oracle_bench_hash_loop_mt(type_.encode(), blobs.ctypes.data, offsets.ctypes.data, lens.ctypes.data, n,
+                                              threads, int(want_libcrypto), int(per_thread_ctx), reps, dig.ctypes.data,
+                                              C.byref(used))
+    return sec, dig, used.value
 
 
 # ------------------------------------------------------- reference doorway --

@@ -5,7 +5,12 @@
 //
 //   option_a_driver helpers                      the helpers that need no device (hex, paths)
 //   option_a_driver store <file>...              writeBlob each file, then writeTree("."), readObject, writeCommit
+//   option_a_driver pipe                         writeTree("."), then close a pipe's write end: its reader must see end-of-file
+//                                                (the store's worker threads must not hold copies of the host program's descriptors)
 #include "object_store.hpp"
+
+#include <poll.h>
+#include <unistd.h>
 
 #include <cstring>
 #include <fstream>
@@ -54,6 +59,19 @@ int main(int argc, char** argv)
         const std::string text = readObjectContent(commit);
         std::cout << "commit " << commit << " tree-line " << (text.compare(0, 5 + 40, "tree " + tree) == 0 ? "ok" : "BAD") << '\n';
         return 0;
+    }
+    if (!std::strcmp(argv[1], "pipe")) {
+        int fd[2];
+        if (::pipe(fd) != 0) return 1;
+        const std::string tree = writeTree(".");            // starts the store's pool, which lives on in the default store
+        if (tree.empty()) return 1;
+        std::cout << "tree " << tree << '\n';
+        ::close(fd[1]);
+        struct pollfd p = {fd[0], POLLIN, 0};
+        char byte;
+        const bool eof = ::poll(&p, 1, 2000) == 1 && ::read(fd[0], &byte, 1) == 0;
+        std::cout << "pipe " << (eof ? "eof" : "STILL-OPEN") << '\n';
+        return eof ? 0 : 1;
     }
     return 2;
 }

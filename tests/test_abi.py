@@ -18,10 +18,16 @@ def lib():
     return _abi.load()
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "vit_hash.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(vit_[a-z0-9_]+)\s*\(", text)))
+HEADERS = ("vit_hash.h", "vit_hash_bench.h")     # the boundary; measurement, test and diagnostic entry points
+
+
+def declared_functions(headers=HEADERS):
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(vit_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_is_plain_c(tmp_path):
@@ -30,11 +36,12 @@ def test_header_is_plain_c(tmp_path):
     import subprocess
     if not shutil.which("gcc"):
         pytest.skip("no gcc here")
-    src = tmp_path / "use.c"
-    src.write_text('#include "vit_hash.h"\nint main(void) { vit_hasher *h = 0; (void)h; return VIT_OK; }\n')
-    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
-                        "-fsyntax-only", str(src)], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
+    for header in HEADERS:
+        src = tmp_path / "use.c"
+        src.write_text('#include "%s"\nint main(void) { vit_hasher *h = 0; (void)h; return VIT_OK; }\n' % header)
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                            "-fsyntax-only", str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
 
 
 def test_library_exports_every_declared_symbol(lib):
@@ -45,6 +52,12 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, n), "libvit_hash.so does not export %s" % n
         assert n in _abi.SIGNATURES, "no ctypes prototype for %s" % n
     assert sorted(_abi.SIGNATURES) == names
+    # what a caller of the reference's object-store functions binds is the first header alone, and it holds no
+    # generator, timer or test hook
+    product = declared_functions(HEADERS[:1])
+    assert 25 <= len(product) <= 32
+    assert not [n for n in product if re.search(r"synth|time_|valu|launch_shape|split_plan|numa|device_(alloc|free|upload|download|sync)", n)]
+    assert "debug_" not in open(os.path.join(ROOT, "include", HEADERS[0])).read().replace("debug_*", "")
 
 
 def test_header_and_block_count(lib, oracle):
@@ -164,8 +177,8 @@ def split(lib, lens, queues=1, threads=16, **over):
     r = dict(RATES, **over)
     lens = np.ascontiguousarray(lens, dtype=np.uint64)
     out = np.zeros(max(len(lens), 1), dtype=np.uint8)
-    rc = lib.vit_host_split_plan(lens.ctypes.data, len(lens), int(r["lane"]), int(r["core"]), int(r["copy"]), int(r["pack"]),
-                                 queues, threads, out.ctypes.data)
+    rc = lib.vit_host_split_plan(lens.ctypes.data, len(lens), int(r["lane"]), int(r["core"]), int(r["copy"]),
+                                 int(r.get("copy_total", 0)), int(r["pack"]), queues, threads, out.ctypes.data)
     assert rc == 0
     return out[:len(lens)].astype(bool)
 
@@ -193,6 +206,10 @@ def test_host_split_plan_balances_the_two_sides(lib):
     assert split(lib, lens, lane=94e6).sum() <= k
     # more queues drain the GPU side faster: fewer objects move; more threads: more do
     assert split(lib, lens, queues=4, threads=16).sum() < k
+    # ... unless the queues share what one of them gets alone (one PCIe link, the host's memory): then as one queue
+    assert split(lib, lens, queues=4, threads=16, copy_total=RATES["copy"]).sum() == k
+    assert split(lib, lens, queues=4, threads=16, copy_total=2 * RATES["copy"]).sum() == split(lib, lens, queues=2, threads=16).sum()
+    assert split(lib, lens, queues=1, copy_total=10 * RATES["copy"]).sum() == k       # never more than the queues' own rates added up
     assert split(lib, lens, threads=4).sum() < k < split(lib, lens, threads=64).sum()
     # skewed (config 4): what moves is a prefix of the (length, index) order: nothing shorter than a moved object stays
     sizes = np.exp(rng.normal(np.log(4500.0), 1.55, 200000))
@@ -208,9 +225,69 @@ def test_host_split_plan_balances_the_two_sides(lib):
     assert 0.7 < host_t / gpu_t < 1.3, (host_t, gpu_t)
     # bad arguments
     one = np.zeros(1, dtype=np.uint8)
-    assert lib.vit_host_split_plan(lens.ctypes.data, 1, 0, 1, 1, 1, 1, 1, one.ctypes.data) == -1
-    assert lib.vit_host_split_plan(lens.ctypes.data, 1, 1, 1, 1, 1, 0, 1, one.ctypes.data) == -1
-    assert lib.vit_host_split_plan(None, 1, 1, 1, 1, 1, 1, 1, one.ctypes.data) == -1
+    assert lib.vit_host_split_plan(lens.ctypes.data, 1, 0, 1, 1, 0, 1, 1, 1, one.ctypes.data) == -1
+    assert lib.vit_host_split_plan(lens.ctypes.data, 1, 1, 1, 1, 0, 1, 0, 1, one.ctypes.data) == -1
+    assert lib.vit_host_split_plan(None, 1, 1, 1, 1, 0, 1, 1, 1, one.ctypes.data) == -1
+
+
+def fake_sysfs(root, gpus, nodes):
+    """gpus: {pci id: node}; nodes: {node: cpulist text}."""
+    for pci, node in gpus.items():
+        d = root / "bus" / "pci" / "devices" / pci
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text("%d\n" % node)
+    for node, cpus in nodes.items():
+        d = root / "devices" / "system" / "node" / ("node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(cpus + "\n")
+
+
+def numa_plan(lib, root, pci_ids, workers):
+    ids = (C.c_char_p * len(pci_ids))(*[p.encode() if p is not None else None for p in pci_ids])
+    qn = (C.c_int * len(pci_ids))()
+    wn = (C.c_int * max(workers, 1))()
+    assert lib.vit_numa_plan(str(root).encode(), ids, len(pci_ids), workers, qn, wn) == 0
+    return list(qn), list(wn)[:workers]
+
+
+def test_numa_plan_on_a_made_up_sysfs_tree(lib, tmp_path):
+    """Which node a GPU hangs off, which CPUs a node has, and where the pool's workers are pinned: read from sysfs
+    files, so a made-up tree stands in for a two-socket, eight-GPU machine."""
+    gpus = {"0000:05:00.0": 0, "0000:15:00.0": 0, "0000:65:00.0": 0, "0000:75:00.0": 0,
+            "0000:85:00.0": 1, "0000:95:00.0": 1, "0000:e5:00.0": 1, "0000:f5:00.0": 1, "0000:aa:00.0": -1}
+    fake_sysfs(tmp_path, gpus, {0: "0-63,128-191", 1: "64-127,192-255", 2: "300"})
+    cpus = (C.c_int * 256)()
+    assert lib.vit_numa_node_cpus(str(tmp_path).encode(), 0, cpus, 256) == 128
+    assert list(cpus)[:128] == list(range(64)) + list(range(128, 192))
+    assert lib.vit_numa_node_cpus(str(tmp_path).encode(), 1, cpus, 4) == 128 and list(cpus)[:4] == [64, 65, 66, 67]
+    assert lib.vit_numa_node_cpus(str(tmp_path).encode(), 7, cpus, 4) == 0            # no such node
+    eight = [p for p in gpus if gpus[p] >= 0]
+    # eight GPUs, four per socket: workers split evenly and handed out in turn
+    qn, wn = numa_plan(lib, tmp_path, eight, 120)
+    assert qn == [0, 0, 0, 0, 1, 1, 1, 1] and wn.count(0) == 60 and wn.count(1) == 60 and wn[:4] == [0, 1, 0, 1]
+    # the hex digits of a bus id may come in upper case
+    assert numa_plan(lib, tmp_path, ["0000:E5:00.0"], 3) == ([1], [1, 1, 1])
+    # three queues on one socket, one on the other: workers in that proportion
+    qn, wn = numa_plan(lib, tmp_path, eight[:3] + eight[4:5], 12)
+    assert qn == [0, 0, 0, 1] and wn.count(0) == 9 and wn.count(1) == 3
+    # every node with a queue gets a worker while workers last
+    qn, wn = numa_plan(lib, tmp_path, eight[:7] + eight[7:], 2)
+    assert sorted(wn) == [0, 1]
+    # one GPU: its node's workers, as long as the node has the CPUs
+    assert numa_plan(lib, tmp_path, eight[:1], 15) == ([0], [0] * 15)
+    # more workers than the node has CPUs, an unknown node, an id that is not there: nobody is pinned
+    assert numa_plan(lib, tmp_path, eight[:1], 200)[1] == [-1] * 200
+    assert numa_plan(lib, tmp_path, eight[:2] + ["0000:aa:00.0"], 8) == ([0, 0, -1], [-1] * 8)
+    assert numa_plan(lib, tmp_path, ["0000:00:99.0", eight[0]], 4) == ([-1, 0], [-1] * 4)
+    assert numa_plan(lib, tmp_path, [None], 2) == ([-1], [-1, -1])
+    assert numa_plan(lib, tmp_path, eight, 0) == ([0, 0, 0, 0, 1, 1, 1, 1], [])
+    ids = (C.c_char_p * 1)(b"x")
+    assert lib.vit_numa_plan(None, ids, 0, 1, (C.c_int * 1)(), (C.c_int * 1)()) == -1
+    # odd cpulist texts
+    fake_sysfs(tmp_path / "odd", {}, {0: "3", 1: "", 2: "5-4", 3: "1,1,2-3,garbage", 4: "0-2,"})
+    for node, want in ((0, [3]), (1, []), (2, []), (3, [1, 2, 3]), (4, [0, 1, 2])):
+        n = lib.vit_numa_node_cpus(str(tmp_path / "odd").encode(), node, cpus, 256)
+        assert list(cpus)[:n] == want, node
 
 
 def test_launch_shape_does_not_wrap_at_the_top_of_the_object_range(lib):

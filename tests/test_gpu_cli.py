@@ -19,6 +19,9 @@ VIT = os.path.join(ROOT, "vit_amd", "bin", "vit")
 def vit(cwd, *args, env=None, check=True, nofile=None):
     e = dict(os.environ)
     e.setdefault("VIT_DEVICES", "0")
+    # these tests are about the device path: no call is too small for it (the store's small-work bound, which keeps
+    # worktrees of this size on host threads by default, has tests/test_store_small_work.py and one test below)
+    e.setdefault("VIT_HOST_CROSSOVER_BYTES", "0")
     if env:
         e.update(env)
     limit = None
@@ -51,6 +54,21 @@ def fresh_copy(src, dst):
 
 def test_binary_exists():
     assert os.path.exists(VIT), "build vit_amd/bin/vit with `python -m vit_amd.build`"
+
+
+def test_both_sides_of_the_small_work_bound(golden_trees, worktrees, tmp_path):
+    """Default bound: the 4 MB worktree of BASELINE configs[0] never starts the HIP runtime; a bound below its size
+    sends the same worktree to the device.  Same root, and --stats says which side made the ids."""
+    rec = golden_trees["c1_1000x4096"]
+    wt = fresh_copy(worktrees["c1_1000x4096"], tmp_path / "host")
+    p = vit(wt, "write-tree", "--stats", env={"VIT_HOST_CROSSOVER_BYTES": ""})
+    assert p.stdout.decode().strip() == rec["root"]
+    assert "ids-on host-threads" in p.stderr.decode() and " 0 ids from the device" in p.stderr.decode()
+    wt = fresh_copy(worktrees["c1_1000x4096"], tmp_path / "gpu")
+    p = vit(wt, "write-tree", "--stats", env={"VIT_HOST_CROSSOVER_BYTES": "1000000"})
+    assert p.stdout.decode().strip() == rec["root"]
+    assert "ids-on gpu" in p.stderr.decode() and " 0 from host threads" in p.stderr.decode()
+    assert "1011 ids from the device" in p.stderr.decode(), p.stderr.decode()
 
 
 def test_write_tree_matches_reference_on_every_golden_worktree(golden_trees, worktrees, tmp_path):

@@ -1,6 +1,7 @@
 """INTEGRATION.md Option A rehearsed: a program that calls the reference's free functions
 (src/commit.hpp:8-25) links against this repository's object_store.cpp instead of the reference's
-commit.cpp.  The helpers need no device (CPU test); the writers go through the GPU hasher."""
+commit.cpp.  The helpers need no device; the writers are run on both sides of the store's small-work bound:
+on the store's own threads (no device, CPU test) and through the GPU hasher."""
 import hashlib
 import os
 import subprocess
@@ -46,16 +47,14 @@ def test_helpers_of_the_reference_interface_need_no_device(oracle, tmp_path):
         assert path.value.decode() == out["path"]
 
 
-@pytest.mark.gpu
-def test_writers_of_the_reference_interface_on_the_gpu(oracle, tmp_path):
-    """writeBlob / writeObject / writeTree / writeCommit / readObject through the free functions."""
+def check_writers(oracle, tmp_path, env):
     wt = tmp_path / "wt"
     (wt / "sub").mkdir(parents=True)
     files = {"a.txt": b"hello\n", "sub/b.bin": oracle.synth_bytes(5, 1, 70000), "empty": b""}
     for name, data in files.items():
         (wt / name).write_bytes(data)
     (wt / ".git" / "objects").mkdir(parents=True)
-    p = run(["store"] + list(files), str(wt))
+    p = run(["store"] + list(files), str(wt), env=env)
     assert p.returncode == 0, p.stdout + p.stderr
     lines = [l.split() for l in p.stdout.splitlines()]
     blobs = [l for l in lines if l[0] == "blob"]
@@ -69,3 +68,31 @@ def test_writers_of_the_reference_interface_on_the_gpu(oracle, tmp_path):
     assert [l for l in lines if l[0] == "emptytree"][0][1] == "4b825dc642cb6eb9a060e54bf8d69288fbee4904"
     commit = [l for l in lines if l[0] == "commit"][0]
     assert len(commit[1]) == 40 and commit[-1] == "ok"
+    return p
+
+
+@pytest.mark.gpu
+def test_writers_of_the_reference_interface_on_the_gpu(oracle, tmp_path):
+    """writeBlob / writeObject / writeTree / writeCommit / readObject through the free functions, every id from the
+    device (VIT_HOST_CROSSOVER_BYTES=0: no call is too small for it)."""
+    check_writers(oracle, tmp_path, {"VIT_HOST_CROSSOVER_BYTES": "0"})
+
+
+def test_writers_of_the_reference_interface_below_the_small_work_bound(oracle, tmp_path):
+    """The same calls with the store's default bound: a few objects are hashed by the store's own threads, the GPU
+    library is not even loaded (the program does not link it), and everything printed and stored is the same."""
+    p = check_writers(oracle, tmp_path, {"VIT_HASH_LIBRARY": "/nonexistent/libvit_hash.so"})
+    assert "GPU" not in p.stderr
+
+
+def test_worker_threads_do_not_pin_the_host_programs_descriptors(oracle, tmp_path):
+    """The store's workers give themselves private descriptor tables, which start as copies of the process's: they must
+    drop those copies, or a pipe the host program closes after a writeTree never reports end-of-file to its reader."""
+    wt = tmp_path / "wt"
+    wt.mkdir()
+    for i in range(40):
+        (wt / ("f%02d" % i)).write_bytes(oracle.synth_bytes(77, i, 3000 + i))
+    (wt / ".git" / "objects").mkdir(parents=True)
+    p = run(["pipe"], str(wt))
+    assert p.returncode == 0 and "pipe eof" in p.stdout, p.stdout + p.stderr
+    assert p.stdout.split()[1] == oracle.write_tree(str(wt), None)[0].hex()

@@ -14,7 +14,7 @@ import bench  # noqa: E402
 import vit_amd  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--queues", type=int, nargs="+", default=[2, 4, 8])
+ap.add_argument("--queues", type=int, nargs="+", default=[1, 2, 4, 8])
 ap.add_argument("--objects", type=int, default=500_000)
 ap.add_argument("--weak", action="store_true", help="N x objects for N queues, as mixed_slice_weak")
 a = ap.parse_args()
@@ -28,5 +28,7 @@ for q in a.queues:
     print(json.dumps({"queues": q, "uniform_4k_matches": out["uniform_4k"]["matches_resident_digests"],
                       "mixed_GBps": m["value"], "objects": m["objects"], "total_ms": m["total_ms"], "plan_ms": m["plan_ms"],
                       "gpu_side_done_ms": m["gpu_side_done_ms"], "host_side_done_ms": m["host_side_done_ms"], "objects_gpu": m["objects_gpu"],
-                      "objects_host": m["objects_host"], "host_threads": m["host_threads"], "matches": m["matches"]}),
+                      "objects_host": m["objects_host"], "host_threads": m["host_threads"],
+                      "copy_rate": m["measured_rates_bytes_per_s"]["copy_rate"], "copy_rate_total": m["copy_rate_total"],
+                      "placement": m["placement"], "matches": m["matches"]}),
           flush=True)

@@ -55,7 +55,18 @@ def main():
         if "FETCH_SIZE" in t:
             fetch = t["FETCH_SIZE"] * 1024 * 2          # KiB -> bytes, x2 gfx950 correction for wide streaming reads
             write = t.get("WRITE_SIZE", 0.0) * 1024
-            json.dump({"kernel": kern, "bytes_per_launch": int(fetch + write), "fetch_bytes_corrected": int(fetch),
+            import subprocess
+            sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            import bench
+            try:
+                commit = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True,
+                                                 cwd=os.path.dirname(os.path.abspath(__file__))).strip()
+            except Exception:
+                commit = None                                # no history on the GPU box: filled in when the summary is copied
+            json.dump({"kernel": kern, "summary": dst + "_pmc.txt", "commit": commit,
+                       "kernel_source_sha256": bench.kernel_source_sha256(),
+                       "objects_per_launch": bench.N_BLOBS, "object_bytes": bench.BLOB_LEN,
+                       "bytes_per_launch": int(fetch + write), "fetch_bytes_corrected": int(fetch),
                        "write_bytes": int(write), "raw_FETCH_SIZE_KiB": t["FETCH_SIZE"],
                        "raw_WRITE_SIZE_KiB": t.get("WRITE_SIZE"),
                        "note": "FETCH_SIZE doubled per the gfx950 calibration (128-B requests tallied at 64 B)"},

@@ -1,4 +1,4 @@
-"""ctypes declarations for include/vit_hash.h (libvit_hash.so).
+"""ctypes declarations for include/vit_hash.h and include/vit_hash_bench.h (libvit_hash.so).
 
 The library is loaded from the package directory only (built in-tree by
 vit_amd.build).  A missing library is an error, never a fallback.
@@ -46,7 +46,9 @@ SIGNATURES = {
     "vit_deflate_objects": (C.c_int, [vp, C.c_char_p, vp, vp, C.c_uint64, vp, C.c_uint64, vp, vp]),
     "vit_deflate_out_bytes": (C.c_uint64, [vp, C.c_char_p, vp, C.c_uint64]),
     "vit_shard_plan": (C.c_int, [vp, C.c_uint64, C.c_int, vp]),
-    "vit_host_split_plan": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp]),
+    "vit_host_split_plan": (C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, vp]),
+    "vit_numa_plan": (C.c_int, [C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vit_numa_node_cpus": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.c_int]),
     "vit_launch_shape": (C.c_int, [C.c_int, C.c_uint64, u32p, u32p]),
     "vit_hash_arena": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp, C.c_uint64, vp]),
     "vit_hash_arena_device": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp, vp]),

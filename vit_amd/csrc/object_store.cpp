@@ -2,6 +2,7 @@
 #include "object_store.hpp"
 
 #include "../../include/vit_hash.h"
+#include "gpu_api.h"
 
 #include <zlib.h>
 
@@ -23,9 +24,11 @@
 #include <sstream>
 #include <thread>
 #include <cerrno>
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <sched.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <unistd.h>
 
 namespace fs = std::filesystem;
@@ -42,12 +45,28 @@ double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now
 // process sixteen threads reading small files get through fewer files per second
 // than four do (measured on tmpfs: 1.0 us per file on 16 threads with the shared
 // table, 0.41 us on 8 with private ones).  A worker only ever uses descriptors it
-// opened itself, so nothing is lost by not seeing the other threads'.
+// opened itself.  The new table starts as a COPY of the process's, and a copy of a
+// descriptor keeps its file open: a pipe the host program closes later would not
+// deliver end-of-file, a lock would stay held, a deleted file would keep its blocks,
+// for as long as the pool lives.  So the worker closes every inherited descriptor
+// above stderr in its own table at once (that closes only its own references).
 thread_local bool tl_private_fd_table = false;
 void privateFdTable()
 {
 #ifdef __linux__
-    tl_private_fd_table = ::unshare(CLONE_FILES) == 0;
+    if (::unshare(CLONE_FILES) != 0) return;
+    tl_private_fd_table = true;
+#ifdef SYS_close_range
+    if (::syscall(SYS_close_range, 3u, ~0u, 0u) == 0) return;
+#endif
+    // an older kernel: close what /proc lists for this thread (the listing's own descriptor goes last)
+    std::vector<int> open_now;
+    std::error_code ec;
+    for (fs::directory_iterator it("/proc/thread-self/fd", ec), end; !ec && it != end; it.increment(ec)) {
+        const int fd = std::atoi(it->path().filename().c_str());
+        if (fd > 2) open_now.push_back(fd);
+    }
+    for (int fd : open_now) ::close(fd);
 #endif
 }
 
@@ -366,6 +385,56 @@ private:
 
 namespace vit {
 
+const GpuApi* GpuApi::load(std::string* why)
+{
+    static std::mutex m;
+    static GpuApi api;
+    static bool tried = false, ok = false;
+    static std::string reason;
+    std::lock_guard<std::mutex> lk(m);
+    if (!tried) {
+        tried = true;
+        std::vector<std::string> where;
+        if (const char* e = std::getenv("VIT_HASH_LIBRARY")) where.push_back(e);
+        else {
+            where.push_back("libvit_hash.so");
+            std::error_code ec;
+            const fs::path exe = fs::read_symlink("/proc/self/exe", ec);
+            if (!ec) {
+                where.push_back((exe.parent_path() / "libvit_hash.so").string());
+                where.push_back((exe.parent_path().parent_path() / "libvit_hash.so").string());
+            }
+        }
+        void* lib = nullptr;
+        for (const std::string& w : where) {
+            lib = ::dlopen(w.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+            const char* e = ::dlerror();
+            reason += (reason.empty() ? "" : "; ") + std::string(e ? e : "dlopen failed");
+        }
+        if (lib) {
+            ok = true;
+            auto sym = [&](const char* name) -> void* {
+                void* p = ::dlsym(lib, name);
+                if (!p) { ok = false; reason = std::string("libvit_hash.so has no ") + name; }
+                return p;
+            };
+            api.hasher_create     = reinterpret_cast<decltype(api.hasher_create)>(sym("vit_hasher_create"));
+            api.hasher_destroy    = reinterpret_cast<decltype(api.hasher_destroy)>(sym("vit_hasher_destroy"));
+            api.last_error        = reinterpret_cast<decltype(api.last_error)>(sym("vit_last_error"));
+            api.set_option        = reinterpret_cast<decltype(api.set_option)>(sym("vit_hasher_set_option"));
+            api.get_stat          = reinterpret_cast<decltype(api.get_stat)>(sym("vit_hasher_get_stat"));
+            api.hash_objects      = reinterpret_cast<decltype(api.hash_objects)>(sym("vit_hash_objects"));
+            api.arena_alloc       = reinterpret_cast<decltype(api.arena_alloc)>(sym("vit_arena_alloc"));
+            api.arena_free        = reinterpret_cast<decltype(api.arena_free)>(sym("vit_arena_free"));
+            api.deflate_objects   = reinterpret_cast<decltype(api.deflate_objects)>(sym("vit_deflate_objects"));
+            api.deflate_out_bytes = reinterpret_cast<decltype(api.deflate_out_bytes)>(sym("vit_deflate_out_bytes"));
+        }
+    }
+    if (!ok && why) *why = reason;
+    return ok ? &api : nullptr;
+}
+
 ObjectStore::ObjectStore(std::string objects_dir, std::vector<int> devices)
     : objects_dir_(std::move(objects_dir)), devices_(std::move(devices))
 {
@@ -373,35 +442,98 @@ ObjectStore::ObjectStore(std::string objects_dir, std::vector<int> devices)
     io_threads_ = int(hw ? std::min(hw, 16u) : 4);
     if (const char* e = std::getenv("VIT_DEFLATE_LEVEL")) setDeflateLevel(std::atoi(e));
     if (const char* e = std::getenv("VIT_DEVICE_DEFLATE")) setDeviceDeflate(std::atoi(e) != 0);
+    if (const char* e = std::getenv("VIT_HOST_CROSSOVER_BYTES")) if (*e) setHostCrossoverBytes(std::strtoull(e, nullptr, 10));
 }
 
 ObjectStore::~ObjectStore()
 {
     pool_.reset();
-    if (deflate_hasher_) vit_hasher_destroy(deflate_hasher_);
-    if (hasher_) vit_hasher_destroy(hasher_);
+    if (deflate_hasher_) gpu_->hasher_destroy(deflate_hasher_);
+    if (hasher_) gpu_->hasher_destroy(hasher_);
 }
 
-// The GPU hasher is made on the first call that hashes: reading objects back
-// (cat-file, ls-tree) needs no device and must work, quietly, without one.
+// The GPU hasher is made by the first call that needs the device: reading objects
+// back (cat-file, ls-tree) never does, and a call whose objects one host core
+// hashes sooner than the HIP runtime starts does not either (sideFor).
 bool ObjectStore::ensureHasher()
 {
     if (hasher_) return true;
     if (hasher_failed_) return false;
-    if (vit_hasher_create(devices_.empty() ? nullptr : devices_.data(), int(devices_.size()), &hasher_) != VIT_OK) {
-        std::cerr << "vit: cannot create the GPU hasher: " << vit_last_error(nullptr) << '\n';
+    std::string why;
+    gpu_ = GpuApi::load(&why);
+    if (!gpu_) {
+        std::cerr << "vit: cannot load the GPU hasher (" << why << "); there is no CPU path for a batch this large\n";
+        hasher_failed_ = true;
+        return false;
+    }
+    if (gpu_->hasher_create(devices_.empty() ? nullptr : devices_.data(), int(devices_.size()), &hasher_) != VIT_OK) {
+        std::cerr << "vit: cannot create the GPU hasher: " << gpu_->last_error(nullptr) << '\n';
         hasher_ = nullptr;
         hasher_failed_ = true;
         return false;
     }
     // Tuning knobs for experiments; the defaults are the library's.
-    if (const char* e = std::getenv("VIT_HOST_THRESHOLD")) vit_hasher_set_option(hasher_, "host_threshold_bytes", std::strtoull(e, nullptr, 10));
-    if (const char* e = std::getenv("VIT_CHUNK_MB")) vit_hasher_set_option(hasher_, "chunk_bytes", std::strtoull(e, nullptr, 10) << 20);
-    if (const char* e = std::getenv("VIT_KERNEL")) vit_hasher_set_option(hasher_, "kernel", std::strtoull(e, nullptr, 10));
+    if (const char* e = std::getenv("VIT_HOST_THRESHOLD")) gpu_->set_option(hasher_, "host_threshold_bytes", std::strtoull(e, nullptr, 10));
+    if (const char* e = std::getenv("VIT_CHUNK_MB")) gpu_->set_option(hasher_, "chunk_bytes", std::strtoull(e, nullptr, 10) << 20);
+    if (const char* e = std::getenv("VIT_KERNEL")) gpu_->set_option(hasher_, "kernel", std::strtoull(e, nullptr, 10));
     // The store's own pool (reads, deflate, writes) keeps the cores busy while a
     // batch is hashed: the hasher's packing threads get a modest share.
-    vit_hasher_set_option(hasher_, "pack_threads", uint64_t(std::max(2, io_threads_ / 2)));
+    gpu_->set_option(hasher_, "pack_threads", uint64_t(std::max(2, io_threads_ / 2)));
     return true;
+}
+
+// Small work never pays for the GPU.  Starting the HIP runtime under a process's first hasher
+// costs 40 ms on a warm machine and up to 180 ms on a cold one (loading the library another 15),
+// more than the reference needs for a whole small worktree.  While this store has no hasher yet, a
+// call whose objects ONE host core would hash within that start-up time is hashed by the store's
+// own threads instead (vit_host_object_ids, four SHA-1 streams interleaved per core).  The bound is
+// measured, not assumed: start-up (the 40 ms of a warm machine) x this machine's one-core rate,
+// about 100 MB with SHA extensions.  A larger call creates the hasher, and from then on every
+// call of the store goes to the device, whose batches cost microseconds once it is up.  This is a
+// scheduling policy of the store, above the C ABI: the library itself still has no CPU path, and a
+// call above the bound on a machine without a gfx950 fails as before.
+uint64_t ObjectStore::hostCrossoverBytes()
+{
+    if (crossover_set_) return crossover_bytes_;
+    static const uint64_t measured = [] {
+        constexpr double kHipStartSeconds = 0.040;
+        std::vector<uint8_t> buf(1u << 20, 0x5A);
+        uint8_t id[20];
+        double best = 1e30;
+        for (int r = 0; r < 2; ++r) {
+            const auto t = clk::now();
+            vit_host_object_id("blob", buf.data(), buf.size(), id);
+            best = std::min(best, since(t));
+        }
+        return uint64_t(kHipStartSeconds * double(buf.size()) / best);
+    }();
+    return measured;
+}
+
+ObjectStore::Side ObjectStore::sideFor(uint64_t bytes)
+{
+    if (hasher_) return Side::GPU;
+    if (crossover_set_ && bytes >= crossover_bytes_) return Side::GPU;          // 0 = always the device
+    if (!crossover_set_ && bytes >= (8u << 20) && bytes >= hostCrossoverBytes()) return Side::GPU;   // under 8 MiB: not worth measuring
+    return Side::HOST;
+}
+
+// ids on the store's threads: slices of consecutive objects, each through vit_host_object_ids.
+void ObjectStore::hashOnHost(const std::string& type, const std::vector<const uint8_t*>& ptr, const std::vector<uint64_t>& len,
+                             uint8_t* out)
+{
+    const size_t n = ptr.size();
+    uint64_t bytes = 0;
+    for (uint64_t l : len) bytes += l;
+    const size_t slices = std::max<size_t>(1, std::min<size_t>({n / 4, size_t(io_threads_) * 4, size_t(bytes >> 16) + 1}));
+    const char* t = type.c_str();
+    auto part = [&](size_t s) {
+        const size_t b = n * s / slices, e = n * (s + 1) / slices;
+        if (b < e) vit_host_object_ids(t, ptr.data() + b, len.data() + b, e - b, out + b * 20);
+    };
+    if (slices == 1) part(0);
+    else pool().run(WorkPool::HIGH, slices, part);
+    stats_.host_hashed += n;
 }
 
 // A second hasher on the same device for the deflate kernel: its own streams and staging memory, so that a
@@ -411,15 +543,20 @@ bool ObjectStore::ensureDeflateHasher()
     if (deflate_hasher_) return true;
     if (deflate_hasher_failed_) return false;
     const int dev = devices_.empty() ? 0 : devices_[0];
-    if (vit_hasher_create(&dev, 1, &deflate_hasher_) != VIT_OK) {
-        std::cerr << "vit: no second hasher for the device deflate (" << vit_last_error(nullptr) << "); deflating on host threads\n";
+    if (!gpu_ || gpu_->hasher_create(&dev, 1, &deflate_hasher_) != VIT_OK) {
+        std::cerr << "vit: no second hasher for the device deflate (" << (gpu_ ? gpu_->last_error(nullptr) : "no GPU library") << "); deflating on host threads\n";
         deflate_hasher_ = nullptr;
         deflate_hasher_failed_ = true;
         return false;
     }
-    vit_hasher_set_option(deflate_hasher_, "pack_threads", uint64_t(std::max(2, io_threads_ / 4)));
-    if (const char* e = std::getenv("VIT_DEVICE_DEFLATE_MAX")) vit_hasher_set_option(deflate_hasher_, "deflate_max_bytes", std::strtoull(e, nullptr, 10));
-    if (std::getenv("VIT_DEBUG_FAIL_DEFLATE")) vit_hasher_set_option(deflate_hasher_, "debug_fail_deflate", 1);   // tests
+    gpu_->set_option(deflate_hasher_, "pack_threads", uint64_t(std::max(2, io_threads_ / 4)));
+    // A batch of the store holds 128 MiB: some 32768 objects of 4 KiB.  That many in flight (5.9 GB of tables on the
+    // device) keeps a launch as short as the library's default of twice as many would.
+    gpu_->set_option(deflate_hasher_, "deflate_lanes", 32768);
+    if (const char* e = std::getenv("VIT_DEVICE_DEFLATE_LANES")) gpu_->set_option(deflate_hasher_, "deflate_lanes", std::strtoull(e, nullptr, 10));
+    if (const char* e = std::getenv("VIT_DEVICE_DEFLATE_MAX")) gpu_->set_option(deflate_hasher_, "deflate_max_bytes", std::strtoull(e, nullptr, 10));
+    if (std::getenv("VIT_DEBUG_FAIL_DEFLATE")) gpu_->set_option(deflate_hasher_, "debug_fail_deflate", 1);       // tests
+    if (std::getenv("VIT_DEBUG_CORRUPT_DEFLATE")) gpu_->set_option(deflate_hasher_, "debug_corrupt_deflate", 1); // tests
     return true;
 }
 
@@ -433,12 +570,12 @@ void ObjectStore::tuneHasher()
 {
     uint64_t min_bytes = store_ ? (256u << 10) : (16u << 10);
     if (const char* e = std::getenv("VIT_HOST_MIN_BYTES")) min_bytes = std::strtoull(e, nullptr, 10);
-    vit_hasher_set_option(hasher_, "host_min_bytes", min_bytes);
+    gpu_->set_option(hasher_, "host_min_bytes", min_bytes);
 }
 
 vit::WorkPool& ObjectStore::pool()
 {
-    if (!pool_ || pool_->threads() != io_threads_ - 1) pool_.reset(new WorkPool(std::max(0, io_threads_ - 1), privateFdTable));
+    if (!pool_ || pool_->threads() != io_threads_ - 1) pool_.reset(new WorkPool(std::max(0, io_threads_ - 1), [](int, int) { privateFdTable(); }));
     return *pool_;
 }
 
@@ -450,20 +587,30 @@ std::string ObjectStore::objectPath(const std::string& hash) const
 bool ObjectStore::hashObjects(const std::string& type, const std::vector<const std::string*>& contents,
                               std::vector<uint8_t>& out)
 {
-    if (!ensureHasher()) return false;
-    tuneHasher();
     const size_t n = contents.size();
     std::vector<const uint8_t*> ptr(n);
     std::vector<uint64_t> len(n);
+    uint64_t bytes = 0;
     for (size_t i = 0; i < n; ++i) {
         ptr[i] = reinterpret_cast<const uint8_t*>(contents[i]->data());
         len[i] = contents[i]->size();
+        bytes += len[i];
     }
     out.resize(n * 20);
-    if (vit_hash_objects(hasher_, type.c_str(), ptr.data(), len.data(), n, out.data()) != VIT_OK) {
-        std::cerr << "vit: hashing failed: " << vit_last_error(hasher_) << '\n';
+    // inside a writeTree the side was chosen once, for the whole worktree
+    const Side side = in_write_tree_ ? tree_side_ : sideFor(bytes);
+    if (side == Side::HOST) {
+        if (vit_header_len(type.c_str(), 0) == 0) { std::cerr << "vit: hashing failed: bad object type\n"; return false; }
+        hashOnHost(type, ptr, len, out.data());
+        return true;
+    }
+    if (!ensureHasher()) return false;
+    tuneHasher();
+    if (gpu_->hash_objects(hasher_, type.c_str(), ptr.data(), len.data(), n, out.data()) != VIT_OK) {
+        std::cerr << "vit: hashing failed: " << gpu_->last_error(hasher_) << '\n';
         return false;
     }
+    stats_.gpu_hashed += n;
     return true;
 }
 
@@ -556,8 +703,24 @@ WorkPool::Ticket ObjectStore::storeAsync(const std::string& type, const std::vec
                     if (err) outcome.failed = 2;
                 };
                 if (dz.buf && dz.len[i]) {                 // the device has made this object's stream already
-                    put(reinterpret_cast<const char*>(dz.buf + dz.off[i]), dz.len[i]);
-                    continue;
+                    // With skip_existing a stored file is never written again, so a stream is looked at before it
+                    // becomes one: no longer than zlib's own bound, zlib's two header bytes for the default level,
+                    // and a trailer that is the Adler-32 of header + content as computed here (a microsecond for
+                    // 4 KiB, beside 20 of file operations).  What fails is deflated by this thread instead.
+                    const uint8_t* z = dz.buf + dz.off[i];
+                    const uint32_t zn = dz.len[i];
+                    char hdr[40];
+                    const int hl = std::snprintf(hdr, sizeof hdr, "%s %llu", type.c_str(), (unsigned long long)c[i].size()) + 1;
+                    uLong ad = adler32(adler32(0L, Z_NULL, 0), reinterpret_cast<const Bytef*>(hdr), uInt(hl));
+                    for (size_t done = 0; done < c[i].size();) {
+                        const size_t take = std::min<size_t>(c[i].size() - done, 1u << 30);
+                        ad = adler32(ad, reinterpret_cast<const Bytef*>(c[i].data() + done), uInt(take));
+                        done += take;
+                    }
+                    const bool sane = zn >= 8 && zn <= compressBound(uLong(size_t(hl) + c[i].size())) && z[0] == 0x78 && z[1] == 0x9c &&
+                                      ((uint32_t(z[zn - 4]) << 24) | (uint32_t(z[zn - 3]) << 16) | (uint32_t(z[zn - 2]) << 8) | z[zn - 1]) == uint32_t(ad);
+                    if (sane) { put(reinterpret_cast<const char*>(z), zn); continue; }
+                    ++outcome.rejected;
                 }
                 std::string z;
                 if (!deflateFramed(level, type, c[i], z)) { outcome.failed = 1; continue; }
@@ -570,6 +733,7 @@ WorkPool::Ticket ObjectStore::storeAsync(const std::string& type, const std::vec
 bool ObjectStore::storeFinished(StoreOutcome& outcome)
 {
     stats_.skipped += outcome.skipped.exchange(0);
+    stats_.device_rejected += outcome.rejected.exchange(0);
     if (outcome.failed == 1) { std::cerr << "Compression failed\n"; return false; }
     if (outcome.failed == 2) { std::cerr << "vit: writing objects under " << objects_dir_ << " failed\n"; return false; }
     return true;
@@ -618,8 +782,6 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
     store_calls_ = nextStoreCall();
     struct InTree { bool& f; InTree(bool& x) : f(x) { f = true; } ~InTree() { f = false; } } in_tree(in_write_tree_);
     const auto t_all = clk::now();
-    if (!ensureHasher()) return {};
-    stats_.init_s = since(t_all);                        // the HIP runtime starting up under the first hasher, mostly
 
     std::vector<DirNode> dirs;
     std::vector<FileRec> files;
@@ -628,6 +790,19 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
     auto t0 = clk::now();
     if (!walk(directoryPath, workers, git_rules_, dirs, files)) return {};
     stats_.walk_s = since(t0);
+
+    // Who computes the ids, decided once for the whole worktree (sideFor): the device, unless this store has no
+    // hasher yet and the files add up to less than one host core hashes while the HIP runtime would start.
+    uint64_t worktree_bytes = 0;
+    for (const FileRec& f : files) worktree_bytes += f.size;
+    tree_side_ = sideFor(worktree_bytes);
+    stats_.ids_on_host = tree_side_ == Side::HOST;
+    stats_.crossover_bytes = crossover_set_ ? crossover_bytes_ : (worktree_bytes >= (8u << 20) ? hostCrossoverBytes() : 0);
+    if (tree_side_ == Side::GPU) {
+        t0 = clk::now();
+        if (!ensureHasher()) return {};
+        stats_.init_s = since(t0);                       // the HIP runtime starting up under the first hasher, mostly
+    }
 
     // ---- blobs, in batches of bounded size, three stages in flight at once:
     //   file reads of batch k+1 (pool, high priority: they feed the GPU)
@@ -639,7 +814,7 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
     // that way is decided batch by batch: the kernel needs tens of thousands of small objects to fill the chip (a
     // launch lasts as long as its longest object on one lane, about 10 us per byte), fewer are done sooner by the
     // host threads.
-    const bool may_device = device_deflate_ && store_ && (deflate_level_ == -1 || deflate_level_ == 6);
+    const bool may_device = tree_side_ == Side::GPU && device_deflate_ && store_ && (deflate_level_ == -1 || deflate_level_ == 6);
     uint64_t device_min_objects = 16384, device_max_bytes = 16384;
     if (const char* e = std::getenv("VIT_DEVICE_DEFLATE_MIN")) device_min_objects = std::strtoull(e, nullptr, 10);
     if (const char* e = std::getenv("VIT_DEVICE_DEFLATE_MAX")) device_max_bytes = std::strtoull(e, nullptr, 10);
@@ -656,10 +831,9 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
         std::vector<uint64_t> zoff; std::vector<uint32_t> zlen;
     } slot[4];
     struct FreePinned {                                   // on every way out
-        vit_hasher* h; Slot* s;
-        ~FreePinned() { for (int k = 0; k < 4; ++k) if (s[k].zbuf) vit_arena_free(h, s[k].zbuf); }
-    } free_pinned{hasher_, slot};
-    std::unique_ptr<SerialWorker> deflater;               // after the slots: joined before they go
+        const GpuApi* gpu; vit_hasher* h; Slot* s;
+        ~FreePinned() { for (int k = 0; k < 4; ++k) if (s[k].zbuf && gpu) gpu->arena_free(h, s[k].zbuf); }
+    } free_pinned{gpu_, hasher_, slot};
     std::vector<std::pair<size_t, size_t>> batches;
     for (size_t pos = 0; pos < files.size();) {
         size_t end = pos;
@@ -680,9 +854,25 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
     // needed again and its batch is still with the device, the device gets less of the next batches; when the device is
     // long done and the host threads are still storing, it gets more.
     std::atomic<bool> device_failed{false};
+    std::atomic<bool> device_checked{false};              // the first batch's streams have been compared with this machine's zlib
     std::atomic<int> device_share{16};
     if (const char* e = std::getenv("VIT_DEVICE_SHARE")) device_share = std::max(1, std::min(16, std::atoi(e)));
     const bool adapt_share = std::getenv("VIT_DEVICE_SHARE") == nullptr;
+    // The pool's tasks and the deflate thread hold pointers into this frame (slots, files, the flags above).  Whatever
+    // way this function is left, an exception on this thread included (out of memory while a batch's views are built),
+    // they have finished first: declared after everything they reference, so destroyed before any of it.
+    std::unique_ptr<SerialWorker> deflater;
+    struct Drain {
+        std::unique_ptr<SerialWorker>& deflater; WorkPool& workers; Slot* s;
+        ~Drain()
+        {
+            deflater.reset();                             // runs what was posted (each posts its batch's stores), then joins
+            for (int k = 0; k < 4; ++k) {
+                if (s[k].read) workers.wait(s[k].read);
+                if (s[k].store) workers.wait(s[k].store);
+            }
+        }
+    } drain{deflater, workers, slot};
     auto finish = [&](Slot& s) {                          // wait for a slot's stores; false if any failed
         double waited_device = 0;
         if (s.deflate.valid()) {
@@ -757,7 +947,7 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
         if (on_device) {
             if (!deflater) deflater.reset(new SerialWorker());
             Slot* sp = &s;
-            s.deflate = deflater->post([this, sp, k, &mark, &device_share, &device_failed] {
+            s.deflate = deflater->post([this, sp, k, &mark, &device_share, &device_failed, &device_checked] {
                 Slot& s = *sp;
                 mark("deflate begins", k);
                 DeviceStreams dz{nullptr, nullptr, nullptr};
@@ -772,24 +962,47 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
                     std::vector<const uint8_t*> ptr(cnt);
                     std::vector<uint64_t> len(cnt);
                     for (size_t j = 0; j < cnt; ++j) { const std::string& c = s.contents[pick[j]]; ptr[j] = reinterpret_cast<const uint8_t*>(c.data()); len[j] = c.size(); }
-                    const uint64_t need = vit_deflate_out_bytes(deflate_hasher_, "blob", len.data(), cnt);
+                    const uint64_t need = gpu_->deflate_out_bytes(deflate_hasher_, "blob", len.data(), cnt);
                     if (need > s.zcap) {
-                        if (s.zbuf) { vit_arena_free(hasher_, s.zbuf); s.zbuf = nullptr; s.zcap = 0; }
-                        if (vit_arena_alloc(hasher_, need + need / 4, &s.zbuf) == VIT_OK) s.zcap = need + need / 4;
+                        if (s.zbuf) { gpu_->arena_free(hasher_, s.zbuf); s.zbuf = nullptr; s.zcap = 0; }
+                        if (gpu_->arena_alloc(hasher_, need + need / 4, &s.zbuf) == VIT_OK) s.zcap = need + need / 4;
                     }
                     std::vector<uint64_t> off(cnt, 0);
                     std::vector<uint32_t> zl(cnt, 0);
                     s.zoff.assign(all, 0); s.zlen.assign(all, 0);
-                    if (need && s.zbuf &&
-                        vit_deflate_objects(deflate_hasher_, "blob", ptr.data(), len.data(), cnt, static_cast<uint8_t*>(s.zbuf), s.zcap,
-                                            off.data(), zl.data()) == VIT_OK) {
-                        for (size_t j = 0; j < cnt; ++j) { s.zoff[pick[j]] = off[j]; s.zlen[pick[j]] = zl[j]; stats_.device_deflated += zl[j] != 0; }
-                        dz = DeviceStreams{static_cast<const uint8_t*>(s.zbuf), s.zoff.data(), s.zlen.data()};
-                    } else if (need) {
+                    bool made = need && s.zbuf &&
+                        gpu_->deflate_objects(deflate_hasher_, "blob", ptr.data(), len.data(), cnt, static_cast<uint8_t*>(s.zbuf), s.zcap,
+                                              off.data(), zl.data()) == VIT_OK;
+                    if (need && !made) {
                         // once is enough: the batches that follow go to the host threads without trying (no memory for
                         // the tables on a GPU that others use, a device error)
                         if (!device_failed.exchange(true))
-                            std::cerr << "vit: deflate on the device failed (" << vit_last_error(deflate_hasher_) << "); zlib on host threads from here on\n";
+                            std::cerr << "vit: deflate on the device failed (" << gpu_->last_error(deflate_hasher_) << "); zlib on host threads from here on\n";
+                    }
+                    // The kernel restates zlib 1.2.11's default-level deflate; the host threads of this same write-tree
+                    // call whatever libz the program is linked with, and the reference's zlib is not pinned at all.  On
+                    // the first batch the device has made, a sample of its streams (the first, the last and six between)
+                    // is compared with what this machine's library gives for the same objects.  Any difference (another
+                    // deflate behind the zlib interface, or a fault on the device) and the device's streams are dropped,
+                    // once and with a message: one store never holds files from two deflates that disagree.
+                    if (made && !device_checked.exchange(true)) {
+                        std::vector<size_t> done;
+                        for (size_t j = 0; j < cnt; ++j) if (zl[j]) done.push_back(j);
+                        for (size_t t = 0; t < 8 && !done.empty() && made; ++t) {
+                            const size_t j = done[(done.size() - 1) * t / 7];
+                            std::string z;
+                            const uint8_t* mine = static_cast<const uint8_t*>(s.zbuf) + off[j];
+                            if (!deflateFramed(deflate_level_, "blob", s.contents[pick[j]], z) || z.size() != zl[j] ||
+                                std::memcmp(z.data(), mine, z.size()) != 0)
+                                made = false;
+                        }
+                        if (!made && !device_failed.exchange(true))
+                            std::cerr << "vit: the device's deflate does not give the bytes of this machine's zlib (" << zlibVersion()
+                                      << "); zlib on host threads from here on\n";
+                    }
+                    if (made && !device_failed.load()) {
+                        for (size_t j = 0; j < cnt; ++j) { s.zoff[pick[j]] = off[j]; s.zlen[pick[j]] = zl[j]; stats_.device_deflated += zl[j] != 0; }
+                        dz = DeviceStreams{static_cast<const uint8_t*>(s.zbuf), s.zoff.data(), s.zlen.data()};
                     }
                     stats_.device_deflate_s += since(t);
                 } catch (const std::exception&) { dz = DeviceStreams{nullptr, nullptr, nullptr}; }      // out of memory: host threads do the batch
@@ -912,6 +1125,8 @@ std::string ObjectStore::readObjectContent(const std::string& hash) const
     const size_t nul = full.find('\0');
     return nul == std::string::npos ? full : full.substr(nul + 1);
 }
+
+const char* zlibVersionString() { return zlibVersion(); }
 
 ObjectStore& defaultStore()
 {

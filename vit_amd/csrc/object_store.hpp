@@ -22,6 +22,7 @@
 #include "work_pool.h"
 
 struct vit_hasher;
+namespace vit { struct GpuApi; }
 
 /* ---------- data structures (reference src/commit.hpp:31-35) ---------- */
 struct TreeEntry {
@@ -35,6 +36,10 @@ namespace vit {
 struct StoreStats {
     uint64_t device_deflated = 0, blobs = 0, trees = 0, bytes = 0;
     uint64_t skipped = 0;                      // objects already in the store (not deflated or written again)
+    uint64_t device_rejected = 0;              // streams the device made that failed the store's checks (deflated again by host threads)
+    uint64_t gpu_hashed = 0, host_hashed = 0;  // ids computed by the device / by the store's own threads (see setHostCrossoverBytes)
+    bool ids_on_host = false;                  // writeTree: which of the two the worktree went to
+    uint64_t crossover_bytes = 0;              // ... and the bound it was compared with (0: so small that none was worked out)
     // writeTree overlaps its stages: read_s = what the hashing thread waited for file reads, hash_s = GPU batches
     // (pack + copy + kernel + read-back), deflate_store_s = from the first batch's hand-over to the last object on disk
     double init_s = 0, walk_s = 0, read_s = 0, hash_s = 0, device_deflate_s = 0, deflate_store_s = 0, trees_s = 0, tree_hash_s = 0, total_s = 0;
@@ -50,7 +55,8 @@ public:
     ObjectStore& operator=(const ObjectStore&) = delete;
 
     // false (with the reason on std::cerr) when no GPU hasher could be created.  The hasher is created by
-    // the first call that needs ids; readObject / readObjectContent never need it.
+    // the first call that needs the device; readObject / readObjectContent never do, and neither does a
+    // call small enough for the store's own threads (setHostCrossoverBytes).
     bool ok() { return ensureHasher(); }
 
     // reference src/commit.cpp:88-114 / :116
@@ -94,6 +100,11 @@ public:
     // (vit_deflate_objects; their longer objects, and smaller batches, still go to host threads), so that the host
     // threads are left with creating files.  Only at the default level: any other level is the host's.
     void setDeviceDeflate(bool on) { device_deflate_ = on; }
+    // While the store has no GPU hasher yet, a call (a writeTree: the whole worktree) of fewer bytes than this has
+    // its ids computed by the store's own threads and starts no HIP runtime.  Default: what one host core hashes in the
+    // 40 ms the runtime takes to start, measured on first need (about 100 MB with SHA extensions).  0: every call goes
+    // to the device.  $VIT_HOST_CROSSOVER_BYTES sets it for the default store.
+    void setHostCrossoverBytes(uint64_t bytes) { crossover_bytes_ = bytes; crossover_set_ = true; }
     void setIoThreads(int n) { io_threads_ = n < 1 ? 1 : n; }
     void setBatchBytes(uint64_t b) { batch_bytes_ = b < 1 ? 1 : b; }
     const StoreStats& lastStats() const { return stats_; }
@@ -101,7 +112,11 @@ public:
     std::string objectPath(const std::string& hash) const;
 
 private:
-    struct StoreOutcome { std::atomic<int> failed{0}; std::atomic<uint64_t> skipped{0}; };   // 1 compression, 2 write
+    struct StoreOutcome { std::atomic<int> failed{0}; std::atomic<uint64_t> skipped{0}, rejected{0}; };   // failed: 1 compression, 2 write
+    enum class Side { GPU, HOST };
+    Side sideFor(uint64_t bytes);                        // who computes the ids of a call of that many bytes
+    uint64_t hostCrossoverBytes();
+    void hashOnHost(const std::string& type, const std::vector<const uint8_t*>& ptr, const std::vector<uint64_t>& len, uint8_t* out);
     bool ensureHasher();
     bool ensureDeflateHasher();
     void tuneHasher();                                   // per call: which objects may leave the GPU for host threads
@@ -116,7 +131,11 @@ private:
     std::vector<int> devices_;
     std::unique_ptr<WorkPool> pool_;
     bool hasher_failed_ = false;
+    const GpuApi* gpu_ = nullptr;                         // libvit_hash.so, loaded with the first hasher
     vit_hasher* hasher_ = nullptr;
+    Side tree_side_ = Side::GPU;                          // during a writeTree: where its ids are computed
+    uint64_t crossover_bytes_ = 0;
+    bool crossover_set_ = false;
     vit_hasher* deflate_hasher_ = nullptr;                // second set of streams and staging, for the device deflate
     bool deflate_hasher_failed_ = false;
     bool store_ = true;
@@ -132,6 +151,9 @@ private:
     std::atomic<uint64_t> store_calls_{0};
     bool in_write_tree_ = false;
 };
+
+// Version of the zlib this program deflates with on the host (zlibVersion()).
+const char* zlibVersionString();
 
 // The store behind the free functions below: ".git/objects" relative to the
 // current directory, devices from $VIT_DEVICES ("0,1,…"; unset = all).

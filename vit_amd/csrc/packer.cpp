@@ -11,6 +11,7 @@
 // message word as a native little-endian dword, so that the kernel swaps
 // nothing (16 vector ops per block that the copy here absorbs for free).
 #include "../../include/vit_hash.h"
+#include "../../include/vit_hash_bench.h"
 #include "host_util.h"
 #include "packer.h"
 
@@ -189,7 +190,9 @@ void plan_host_split(const uint64_t* len, uint64_t n, const SplitRates& r, int q
         if (src != cand.data()) std::memcpy(cand.data(), src, cand.size() * sizeof(Cand));
     }
     const double nt = double(threads);
-    const double queue_rate = std::min(0.8 * r.copy * double(queues), r.pack * nt);
+    double copy_all = r.copy * double(queues);
+    if (r.copy_total > 0) copy_all = std::min(copy_all, r.copy_total);     // queues that share a link or the host's memory
+    const double queue_rate = std::min(0.8 * copy_all, r.pack * nt);
     const double longest = double(cand[0].len);
     double gpu_bytes = double(total), host_bytes = 0;
     size_t moved = 0;
@@ -292,14 +295,15 @@ int vit_bin_order(const uint32_t* nblocks, uint64_t n, uint32_t* order)
 }
 
 int vit_host_split_plan(const uint64_t* len, uint64_t n, uint64_t lane_rate, uint64_t core_rate, uint64_t copy_rate,
-                        uint64_t pack_rate, int n_queues, int threads, uint8_t* on_host)
+                        uint64_t copy_rate_total, uint64_t pack_rate, int n_queues, int threads, uint8_t* on_host)
 {
     if (n && (!len || !on_host)) return VIT_ERR_ARG;
     if (!lane_rate || !core_rate || !copy_rate || !pack_rate || n_queues < 1 || threads < 1) return VIT_ERR_ARG;
     try {
         std::vector<uint64_t> moved;
-        vit::plan_host_split(len, n, vit::SplitRates{double(lane_rate), double(core_rate), double(copy_rate), double(pack_rate)},
-                             n_queues, threads, moved);
+        vit::SplitRates rates{double(lane_rate), double(core_rate), double(copy_rate), double(pack_rate)};
+        rates.copy_total = double(copy_rate_total);
+        vit::plan_host_split(len, n, rates, n_queues, threads, moved);
         std::memset(on_host, 0, size_t(n));
         for (uint64_t i : moved) on_host[i] = 1;
         return VIT_OK;

@@ -41,7 +41,9 @@ bool bin_order(const uint32_t* nblocks, uint64_t n, uint32_t* order);
 // min_bytes: objects shorter than this never move (default kHostSplitMin).
 // host_bias: factor on the host side's estimated time (1 = the model as it is; the hasher learns
 // it from when the two sides of its earlier calls finished).
-struct SplitRates { double lane, core, copy, pack; double core_multi = 0; uint64_t min_bytes = 16u << 10; double host_bias = 1; };
+// copy_total (0 = none measured): what all the queues get when they copy at once; the GPU side
+// drains at 0.8 x min(queues x copy, copy_total).
+struct SplitRates { double lane, core, copy, pack; double core_multi = 0; uint64_t min_bytes = 16u << 10; double host_bias = 1; double copy_total = 0; };
 constexpr uint64_t kHostSplitMin = 16u << 10;
 // parallel_for (optional): runs fn(0) .. fn(parts - 1) on the caller's threads and returns when all have; the
 // scan of a large batch for candidates is cut into parts with it.

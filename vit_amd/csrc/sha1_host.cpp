@@ -1,6 +1,9 @@
 // sha1_host.cpp — streaming SHA-1 on a host core (see sha1_host.h for its role).
 #include "sha1_host.h"
 
+#include "../../include/vit_hash.h"
+#include "packer.h"
+
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -271,3 +274,23 @@ void host_object_ids(const char* type, const uint8_t* const* content, const uint
 }
 
 }  // namespace vit
+
+/* ---------- C ABI (include/vit_hash.h): the host lane on its own, no device needed ---------- */
+extern "C" {
+
+int vit_host_object_id(const char* type, const uint8_t* data, uint64_t len, uint8_t* digest)
+{
+    if (!vit::type_len_checked(type) || !digest || (len && !data)) return VIT_ERR_ARG;
+    vit::host_object_id(type, data, len, digest);
+    return VIT_OK;
+}
+
+int vit_host_object_ids(const char* type, const uint8_t* const* data, const uint64_t* len, uint64_t n, uint8_t* digests)
+{
+    if (!vit::type_len_checked(type) || (n && (!data || !len || !digests))) return VIT_ERR_ARG;
+    for (uint64_t i = 0; i < n; ++i) if (len[i] && !data[i]) return VIT_ERR_ARG;
+    vit::host_object_ids(type, data, len, size_t(n), digests);
+    return VIT_OK;
+}
+
+}  // extern "C"

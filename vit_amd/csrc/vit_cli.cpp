@@ -88,6 +88,9 @@ bool cmdWriteTree(int argc, char** argv)
     if (stats) {
         const vit::StoreStats& s = vit::defaultStore().lastStats();
         std::cerr << "blobs " << s.blobs << " trees " << s.trees << " bytes " << s.bytes << " already-stored " << s.skipped
+                  << " | ids-on " << (s.ids_on_host ? "host-threads" : "gpu") << " (crossover " << s.crossover_bytes << " bytes; " << s.gpu_hashed
+                  << " ids from the device, " << s.host_hashed << " from host threads) zlib " << vit::zlibVersionString()
+                  << " device-streams-rejected " << s.device_rejected
                   << " | init " << s.init_s << " s walk " << s.walk_s
                   << " s read-wait " << s.read_s << " s hash " << s.hash_s << " s device-deflate " << s.device_deflate_s << " s (" << s.device_deflated
                   << " objects) blobs-pipeline(read|hash|deflate+store) " << s.deflate_store_s

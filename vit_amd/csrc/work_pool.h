@@ -12,6 +12,12 @@
 // low-priority group.  The thread that waits for a group helps with that group's
 // tasks, so a group completes even on a pool of zero threads and a waiting
 // thread is not idle.
+//
+// Placement: a worker may carry a node (the NUMA node its thread is pinned to) and
+// a group may name the node it would like to run on (the node of the memory it
+// writes).  A worker with a node takes the oldest high-priority group of its own
+// node or of no node first and only then any other high-priority group: work is
+// never left waiting for the right thread, it only goes to the right thread first.
 #pragma once
 #include <atomic>
 #include <condition_variable>
@@ -31,16 +37,20 @@ public:
     struct Group {
         std::function<void(size_t)> fn;
         size_t n = 0;
+        int node = -1;                   // preferred node of the workers that run it; -1 = any
         size_t next = 0;                 // next unclaimed task (guarded by the pool's mutex)
         size_t done = 0;                 // finished tasks (guarded by the pool's mutex)
         std::condition_variable finished;
     };
     using Ticket = std::shared_ptr<Group>;
 
-    // on_thread_start, when given, runs once at the start of every worker thread.
-    explicit WorkPool(int threads, std::function<void()> on_thread_start = nullptr) : on_start_(std::move(on_thread_start))
+    // on_thread_start, when given, runs once at the start of every worker thread with the worker's index
+    // and node (it is what pins the thread, if anything does).
+    explicit WorkPool(int threads, std::function<void(int worker, int node)> on_thread_start = nullptr,
+                      std::vector<int> worker_node = {})
+        : on_start_(std::move(on_thread_start))
     {
-        resize(threads);
+        resize(threads, std::move(worker_node));
     }
     ~WorkPool() { stop(); }
     WorkPool(const WorkPool&) = delete;
@@ -53,20 +63,26 @@ public:
     int peak_busy() const { return peak_busy_.load(); }
     void reset_peak() { peak_busy_ = 0; }
 
-    // Stop the workers and start `threads` new ones.  Only between batches.
-    void resize(int threads)
+    // Stop the workers and start `threads` new ones; worker w gets node worker_node[w] (-1, or
+    // no entry: none).  Only between batches.
+    void resize(int threads, std::vector<int> worker_node = {})
     {
         stop();
         stop_ = false;
-        for (int i = 0; i < threads; ++i) workers_.emplace_back([this] { work(); });
+        worker_node.resize(size_t(threads < 0 ? 0 : threads), -1);
+        for (int i = 0; i < threads; ++i) {
+            const int node = worker_node[size_t(i)];
+            workers_.emplace_back([this, i, node] { work(i, node); });
+        }
     }
 
-    // Queue fn(0) .. fn(n-1); returns at once.  fn must not throw.
-    Ticket submit(Priority prio, size_t n, std::function<void(size_t)> fn)
+    // Queue fn(0) .. fn(n-1); returns at once.  fn must not throw.  node: see "Placement" above.
+    Ticket submit(Priority prio, size_t n, std::function<void(size_t)> fn, int node = -1)
     {
         Ticket g = std::make_shared<Group>();
         g->fn = std::move(fn);
         g->n = n;
+        g->node = node;
         if (n == 0) return g;
         {
             std::lock_guard<std::mutex> lk(m_);
@@ -93,7 +109,7 @@ public:
     }
 
     // submit + wait.
-    void run(Priority prio, size_t n, std::function<void(size_t)> fn) { wait(submit(prio, n, std::move(fn))); }
+    void run(Priority prio, size_t n, std::function<void(size_t)> fn, int node = -1) { wait(submit(prio, n, std::move(fn), node)); }
 
 private:
     void drop(const Ticket& g)           // with m_ held: the group has no unclaimed task left
@@ -103,14 +119,25 @@ private:
                 if (*it == g) { q.erase(it); return; }
     }
 
-    void work()
+    // with m_ held: the oldest group of that priority this worker should take first, or null
+    Ticket local(Priority prio, int my_node) const
     {
-        if (on_start_) on_start_();
+        for (const Ticket& g : open_[prio])
+            if (g->node < 0 || my_node < 0 || g->node == my_node) return g;
+        return nullptr;
+    }
+
+    void work(int index, int my_node)
+    {
+        if (on_start_) on_start_(index, my_node);
         std::unique_lock<std::mutex> lk(m_);
         for (;;) {
             wake_.wait(lk, [this] { return stop_ || !open_[HIGH].empty() || !open_[LOW].empty(); });
             if (stop_) return;
-            Ticket g = !open_[HIGH].empty() ? open_[HIGH].front() : open_[LOW].front();
+            Ticket g = local(HIGH, my_node);
+            if (!g && !open_[HIGH].empty()) g = open_[HIGH].front();
+            if (!g) g = local(LOW, my_node);
+            if (!g) g = open_[LOW].front();
             const size_t i = g->next++;
             if (g->next == g->n) drop(g);
             const int busy = ++busy_;
@@ -132,7 +159,7 @@ private:
         workers_.clear();
     }
 
-    std::function<void()> on_start_;
+    std::function<void(int, int)> on_start_;
     std::vector<std::thread> workers_;
     std::deque<Ticket> open_[2];
     std::mutex m_;
