@@ -319,19 +319,23 @@ int vit_hash_arena_device(vit_hasher *h, int dev, const void *d_arena, uint64_t 
                           const uint32_t *d_order, uint64_t n, uint8_t *d_digests,
                           void *stream);
 
-/* The same launch for callers that cannot allocate (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc): it length-bins
+/* The same launch for callers that cannot allocate (tight serving loops, harnesses
+ * that forbid hipMalloc, code that must not perturb the device allocator): it length-bins
  * the batch on the device and hashes it in that order, like vit_bin_order_device
  * followed by vit_hash_arena_device, but calls no hipMalloc/hipFree or any
  * allocating routine.  The order array, the binning counters and the status
  * word live in a file-scope device array inside the library: about 8 MiB that
  * every GPU the library runs on holds until the process ends.  Limit: n <=
  * VIT_STATIC_MAX_OBJECTS per call (VIT_ERR_RANGE beyond, nothing launched).
- * All calls on one GPU share that GPU's array: calls that overlap in time on
- * one GPU (two streams, two queues on the same ordinal, two hashers) race;
- * calls ordered one after the other are independent of each other, whatever
- * their sizes.  Digests are those of vit_hash_arena_device.  Asynchronous on
- * `stream`; status bits are read and cleared by vit_device_status.
+ * All calls on one GPU share that GPU's array, so the library runs them one after
+ * the other: each call's launches wait, on the device, for the previous call's
+ * (through one event per GPU, made when the GPU's first queue is; a lock keeps two
+ * host threads' calls from interleaving), whatever hasher, queue or stream they
+ * come through.  Calls on one GPU therefore never overlap each other; they
+ * overlap everything else.  A stream under graph capture is not supported: the
+ * event that orders the calls would be captured with it.  Digests are those of
+ * vit_hash_arena_device.  Asynchronous on `stream`; status bits are read and
+ * cleared by vit_device_status.
  * No counterpart in the reference (its SHA1() call allocates nothing and has no
  * device state, src/commit.cpp:93-94). */
 #define VIT_STATIC_MAX_OBJECTS (1u << 21)

@@ -87,6 +87,10 @@ int vit_synth_arena_device(vit_hasher *h, int dev, const char *type, uint64_t se
                            void *d_arena, uint64_t arena_bytes, void *stream);
 /* Host restatement of the same byte stream (for checking the generator). */
 void vit_synth_bytes(uint64_t seed, uint64_t index, uint8_t *dst, uint64_t len);
+/* ... for n objects in one call, on `threads` threads: object i = stream (seed, first_index + i),
+ * lens[i] bytes at dst + offsets[i].  For workloads of millions of objects in host memory. */
+int vit_synth_fill_host(uint64_t seed, uint64_t first_index, uint64_t n, const uint64_t *lens,
+                        const uint64_t *offsets, uint8_t *dst, int threads);
 
 /* Launch the device-resident hash `iters` times after `warmup` untimed
  * launches and report each launch's duration in milliseconds, measured with

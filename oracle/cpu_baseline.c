@@ -205,3 +205,31 @@ void vit_oracle_synth_fill_many(uint64_t seed, uint64_t first, uint64_t n, uint6
     }
     for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
 }
+
+/* The same for objects of different lengths: object i (stream index first+i) at dst + offsets[i], lens[i] bytes. */
+typedef struct { uint64_t seed, first, begin, end; const uint64_t *lens, *offsets; uint8_t *dst; } fillv_t;
+static void *fillv_main(void *arg)
+{
+    fillv_t *f = (fillv_t *)arg;
+    for (uint64_t i = f->begin; i < f->end; ++i)
+        vit_oracle_synth_fill(f->seed, f->first + i, f->dst + f->offsets[i], f->lens[i]);
+    return NULL;
+}
+void vit_oracle_synth_fill_var(uint64_t seed, uint64_t first, uint64_t n, const uint64_t *lens,
+                               const uint64_t *offsets, uint8_t *dst, int threads)
+{
+    if (threads < 1) threads = 1;
+    if (threads > 256) threads = 256;
+    pthread_t tid[256]; fillv_t f[256];
+    /* ranges of about equal bytes: offsets[] ascend */
+    uint64_t total = n ? offsets[n - 1] + lens[n - 1] : 0, at = 0;
+    for (int t = 0; t < threads; ++t) {
+        uint64_t end = at;
+        uint64_t goal = total / (uint64_t)threads * (uint64_t)(t + 1);
+        while (end < n && (t == threads - 1 || offsets[end] < goal)) ++end;
+        f[t] = (fillv_t){ seed, first, at, end, lens, offsets, dst };
+        pthread_create(&tid[t], NULL, fillv_main, &f[t]);
+        at = end;
+    }
+    for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+}

@@ -49,6 +49,7 @@ def lib():
         L.vit_oracle_synth_fill.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]
         L.vit_oracle_synth_fill_many.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                                  C.c_void_p, C.c_int]
+        L.vit_oracle_synth_fill_var.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.vit_oracle_have_libcrypto.restype = C.c_int
         L.vit_oracle_libcrypto_sha1.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.vit_oracle_bench_hash_loop.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -81,6 +82,11 @@ def ref_lib():
         R.vitref_read_object_content.restype = C.c_uint64
         R.vitref_read_object.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64]
         R.vitref_read_object.restype = C.c_uint64
+        if hasattr(R, "vitref_parse_tree"):
+            R.vitref_parse_tree.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64]
+            R.vitref_parse_tree.restype = C.c_uint64
+            R.vitref_files_in_directory.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64]
+            R.vitref_files_in_directory.restype = C.c_uint64
         _REF = R
     return _REF
 
@@ -220,6 +226,14 @@ def synth_fill_many(seed, first, n, len_each, threads=8):
     return arr
 
 
+def synth_fill_var(seed, first, lens, offsets, out, threads=8):
+    """Objects of different lengths into `out` (numpy uint8): object i = stream (seed, first + i) at offsets[i]."""
+    lens = np.ascontiguousarray(lens, dtype=np.uint64)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    lib().vit_oracle_synth_fill_var(seed, first, len(lens), lens.ctypes.data, offsets.ctypes.data, out.ctypes.data, threads)
+    return out
+
+
 def bench_hash_loop(blobs, offsets, lens, threads=1, want_libcrypto=True, type_="blob"):
     """Time the reference-equivalent hashing loop (src/commit.cpp:90-94).
     Returns (seconds, digests[n,20], used_libcrypto)."""
@@ -277,3 +291,20 @@ def ref_write_tree(path):
     if R.vitref_write_tree(os.fsencode(path), out) != 0:
         return ""
     return out.value.decode()
+
+
+def ref_parse_tree(hex_id):
+    """The reference's parseTree (needs CWD with .git/objects): list of (mode, name, hex id, is_directory), bytes."""
+    R = ref_lib()
+    buf = C.create_string_buffer(1 << 20)
+    n = R.vitref_parse_tree(hex_id.encode(), buf, len(buf))
+    fields = buf.raw[:n].split(b"\0")[:-1]
+    return [(fields[i], fields[i + 1], fields[i + 2].decode(), fields[i + 3] == b"d") for i in range(0, len(fields), 4)]
+
+
+def ref_files_in_directory(directory="."):
+    """The reference's FileUtils::getFilesInDirectory: list of paths (bytes), in its order."""
+    R = ref_lib()
+    buf = C.create_string_buffer(1 << 22)
+    n = R.vitref_files_in_directory(os.fsencode(directory), buf, len(buf))
+    return buf.raw[:n].split(b"\0")[:-1]

@@ -1,7 +1,7 @@
 // ref_shim.cpp — C-callable doorway into the reference's own object-store code.
 //
 // TEST INFRASTRUCTURE ONLY.  This file is compiled TOGETHER WITH the reference's
-// src/commit.cpp and src/branch.cpp, taken where they lie under /root/reference
+// src/commit.cpp, src/branch.cpp and src/utils/file_utils.cpp, taken where they lie under /root/reference
 // (never copied into this repository), into oracle/_ref/libvitref.so by
 // oracle/Makefile.  It contains no algorithm: each function forwards to the
 // reference function named in its comment.  Used to pin the CPU restatement
@@ -10,6 +10,7 @@
 // The reference's writeObject() stores into the CWD-relative ".git/objects/"
 // (src/commit.cpp:108-111), so callers chdir() into a scratch repository first.
 #include "commit.hpp"
+#include "utils/file_utils.hpp"
 
 #include <cstdint>
 #include <cstring>
@@ -81,6 +82,31 @@ uint64_t vitref_read_object(const char* hex, void* out, uint64_t cap)
     std::string c = readObject(hex);
     std::memcpy(out, c.data(), c.size() < cap ? c.size() : cap);
     return c.size();
+}
+
+// parseTree, src/commit.cpp:175-200.  Every entry as four NUL-terminated fields (mode, name, hex id,
+// "d" or "f"); returns the bytes that takes, copies at most cap of them.
+uint64_t vitref_parse_tree(const char* hex, void* out, uint64_t cap)
+{
+    std::string flat;
+    for (const FileInfo& f : parseTree(hex)) {
+        flat += f.mode; flat += '\0';
+        flat += f.name; flat += '\0';
+        flat += f.hash; flat += '\0';
+        flat += f.isDirectory ? "d" : "f"; flat += '\0';
+    }
+    std::memcpy(out, flat.data(), flat.size() < cap ? flat.size() : cap);
+    return flat.size();
+}
+
+// FileUtils::getFilesInDirectory, src/utils/file_utils.cpp:55-80.  The paths, each NUL-terminated;
+// returns the bytes that takes, copies at most cap of them.
+uint64_t vitref_files_in_directory(const char* dir, void* out, uint64_t cap)
+{
+    std::string flat;
+    for (const std::string& p : vit::utils::FileUtils::getFilesInDirectory(dir)) { flat += p; flat += '\0'; }
+    std::memcpy(out, flat.data(), flat.size() < cap ? flat.size() : cap);
+    return flat.size();
 }
 
 }  // extern "C"

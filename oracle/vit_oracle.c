@@ -289,7 +289,9 @@ int vit_oracle_write_tree(const char *dir, const char *objects_dir, uint8_t out[
         vit_oracle_tree_entry *e = &ents[n];
         if (S_ISREG(st.st_mode)) {                                  /* :150-154 */
             uint8_t *data; size_t len;
-            if (slurp(path, &data, &len)) { rc = -1; break; }
+            /* :151-152: a file that cannot be opened leaves the reference's stringstream empty, and the empty
+             * string is hashed and stored like any other content: the entry points at the empty blob. */
+            if (slurp(path, &data, &len)) { data = (uint8_t *)malloc(1); len = 0; }
             if (objects_dir) {
                 if (vit_oracle_store_object(objects_dir, "blob", data, len, e->id)) { free(data); rc = -1; break; }
             } else vit_oracle_object_id("blob", data, len, e->id);

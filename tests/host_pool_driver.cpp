@@ -21,7 +21,7 @@ int main()
     std::vector<std::atomic<int>> low_hits(400);
     std::atomic<int> low_done{0};
     auto low = pool.submit(vit::WorkPool::LOW, low_hits.size(), [&](size_t i) {
-        enter(); std::this_thread::sleep_for(std::chrono::microseconds(300)); ++low_hits[i]; ++low_done; leave();
+        enter(); std::this_thread::sleep_for(std::chrono::microseconds(1500)); ++low_hits[i]; ++low_done; leave();
     });
     // high priority from four submitting threads, each 30 groups of 16 tasks
     std::atomic<long> high_sum{0};
@@ -45,9 +45,37 @@ int main()
     // the helpers (4 submitting threads + main) run tasks too: at most pool threads + helpers at once
     if (peak > kThreads + kQueues + 1) { std::printf("peak %d threads in tasks\n", peak.load()); return 1; }
     if (pool.peak_busy() > kThreads) { std::printf("pool peak %d > %d\n", pool.peak_busy(), kThreads); return 1; }
-    // 1920 quick high-priority tasks finished while the 400 x 300 us of low-priority work (20 ms on 6 threads) was
+    // 1920 quick high-priority tasks finished while the 400 x 1500 us of low-priority work (100 ms on 6 threads) was
     // still going on: they were not queued behind it
     if (low_done_when_high_finished >= 400) { std::printf("high-priority groups waited for the low-priority one\n"); return 1; }
+    // Placement: workers 0-2 carry node 0, workers 3-5 node 1.  A group that names a node goes to that node's
+    // workers first, but is never left waiting for them: every task runs once even when only the other node's
+    // workers are free (node 7 has no worker at all), and help() runs a group's tasks on a thread that is not in
+    // the pool and says when none are left.
+    {
+        thread_local int my_node = -2;
+        vit::WorkPool placed(6, [](int, int node) { my_node = node; }, std::vector<int>{0, 0, 0, 1, 1, 1});
+        std::atomic<int> ran{0}, local{0}, helped{0};
+        std::vector<vit::WorkPool::Ticket> tickets;
+        for (int g = 0; g < 40; ++g) {
+            const int node = g % 4 == 3 ? 7 : g % 2;
+            tickets.push_back(placed.submit(vit::WorkPool::HIGH, 25, [&, node](size_t) {
+                std::this_thread::sleep_for(std::chrono::microseconds(50));
+                ++ran;
+                if (my_node == node) ++local;
+            }, node));
+        }
+        auto low2 = placed.submit(vit::WorkPool::LOW, 200, [&](size_t) { if (my_node == -2) ++helped; ++ran; });
+        while (placed.help(low2)) {}                       // this thread is no worker: my_node stays -2
+        if (placed.help(low2)) { std::printf("help() found a task in a group with none left\n"); return 1; }
+        for (auto& t : tickets) placed.wait(t);
+        placed.wait(low2);
+        if (ran != 40 * 25 + 200) { std::printf("placed groups: %d tasks ran\n", ran.load()); return 1; }
+        if (helped == 0) { std::printf("help() ran nothing\n"); return 1; }
+        // 30 of the 40 groups name node 0 or 1: most of their 750 tasks should have run on their own node's workers
+        if (local < 375) { std::printf("only %d of 750 tasks ran on their own node\n", local.load()); return 1; }
+        std::printf("placement: %d of 750 node-tagged tasks ran on their node, %d low tasks by the helping thread\n", local.load(), helped.load());
+    }
     // resize, empty groups, a pool that must be helped
     pool.resize(1);
     pool.run(vit::WorkPool::LOW, 0, [](size_t) {});

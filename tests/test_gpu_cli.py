@@ -149,6 +149,47 @@ def test_device_deflate_failing_leaves_the_work_to_the_host(golden_trees, worktr
     assert set(golden_trees[name]["blob_ids"]) <= set(objs) and set(golden_trees[name]["tree_ids"]) <= set(objs)
 
 
+def test_device_deflate_that_differs_from_this_machines_zlib_is_dropped(oracle, golden_trees, worktrees, tmp_path):
+    """The kernel restates zlib 1.2.11; the host threads of the same write-tree call whatever libz is linked.  The first
+    batch the device makes is compared with the linked library on a sample that includes its first stream; here the
+    library flips one byte in the middle of that stream (debug_corrupt_deflate: the Adler-32 trailer stays intact, as
+    after a fault in the deflate itself).  One message, the device's streams dropped, every stored file the oracle's."""
+    name = [k for k in golden_trees if golden_trees[k].get("spec") == "skew"][0]
+    wt = fresh_copy(worktrees[name], tmp_path / "ddcorrupt")
+    p = vit(wt, "write-tree", "--stats", env={"VIT_DEVICE_DEFLATE": "1", "VIT_DEVICE_DEFLATE_MIN": "1", "VIT_BATCH_MB": "8",
+                                              "VIT_DEBUG_CORRUPT_DEFLATE": "1"})
+    assert p.stdout.decode().strip() == golden_trees[name]["root"]
+    err = p.stderr.decode()
+    assert err.count("does not give the bytes of this machine's zlib") == 1 and " s (0 objects)" in err, err
+    assert "zlib %s" % zlib.ZLIB_RUNTIME_VERSION in err
+    ref_dir = tmp_path / "oracle_objects"
+    oracle.write_tree(worktrees[name], str(ref_dir))
+    n = 0
+    for d in os.listdir(ref_dir):
+        for f in os.listdir(ref_dir / d):
+            assert open(os.path.join(wt, ".git", "objects", d, f), "rb").read() == open(ref_dir / d / f, "rb").read(), d + f
+            n += 1
+    assert n >= len(set(golden_trees[name]["blob_ids"]))
+
+
+def test_stream_with_a_bad_trailer_is_deflated_again_by_the_host(oracle, golden_trees, worktrees, tmp_path):
+    """Beyond the first batch's comparison, every device-made stream is looked at before it becomes a file that is
+    never written again: length within zlib's bound, zlib's header bytes, a trailer equal to the Adler-32 of header +
+    content.  VIT_DEBUG_BAD_TRAILER makes the store see a wrong trailer on every 100th stream: those objects are
+    deflated by the host thread instead, counted, and the files are the oracle's."""
+    name = "c1_1000x4096"
+    wt = fresh_copy(worktrees[name], tmp_path / "badtrailer")
+    p = vit(wt, "write-tree", "--stats", env={"VIT_DEVICE_DEFLATE": "1", "VIT_DEVICE_DEFLATE_MIN": "1", "VIT_DEBUG_BAD_TRAILER": "100"})
+    assert p.stdout.decode().strip() == golden_trees[name]["root"]
+    rejected = int(p.stderr.decode().split("device-streams-rejected ")[1].split()[0])
+    assert 5 <= rejected <= 20, p.stderr.decode()
+    ref_dir = tmp_path / "oracle_objects"
+    oracle.write_tree(worktrees[name], str(ref_dir))
+    for d in os.listdir(ref_dir):
+        for f in os.listdir(ref_dir / d):
+            assert open(os.path.join(wt, ".git", "objects", d, f), "rb").read() == open(ref_dir / d / f, "rb").read(), d + f
+
+
 def test_write_tree_with_fewer_descriptors_than_fanout_directories(golden_trees, worktrees, tmp_path):
     """The storing threads keep a handle per objects/xx directory; where the descriptor limit is below the 256 of
     them (plus what the runtime holds), they give handles back and carry on: same id, every object stored."""
@@ -256,6 +297,30 @@ def test_diff_tree_finds_changes_by_id(oracle, golden_trees, worktrees, tmp_path
     commit = vit(wt, "commit-tree", root, "-p", "", "-m", "m", env={"VIT_COMMIT_TIME": "1"}).stdout.decode().strip()
     assert vit(wt, "diff-tree", commit).stdout == p.stdout
     assert vit(wt, "diff-tree", "0" * 40, check=False).returncode == 1
+
+
+def test_diff_tree_after_500_random_changes_matches_the_oracle_with_ids_from_the_device(golden_trees, worktrees, tmp_path):
+    """Row f4 against an oracle: oracle/change_oracle.py restates the reference's ChangeAnalyzer, which inflates every
+    committed blob and compares CONTENTS (src/utils/change_analyzer.cpp:85-88); `vit diff-tree` compares the ids of one
+    GPU batch over the worktree with the ids in the tree.  Same modified and deleted records after >= 500 random edits,
+    deletions and additions to the 10,000-file skewed worktree, an identical rewrite, an emptied file and a name with
+    a space (tests/_change_cases.py); added files = the records the reference builds and drops (:62-72)."""
+    from oracle import change_oracle
+    from _change_cases import mutate, run_and_compare
+    name = [k for k in golden_trees if golden_trees[k].get("spec") == "skew"][0]
+    wt = str(tmp_path / "wt")
+    shutil.copytree(worktrees[name], wt)
+    open(os.path.join(wt, "t00", "a name with spaces.txt"), "wb").write(b"spaced\n")
+    vit(wt, "init")
+    p = vit(wt, "write-tree", "--stats")
+    assert "ids-on gpu" in p.stderr.decode()
+    root = p.stdout.decode().strip()
+    files = sorted(os.path.relpath(os.path.join(d, f), wt) for d, _, fs in os.walk(wt) for f in fs
+                   if ".git" not in d and " " not in f)
+    expect = mutate(wt, files, seed=12)
+    got = run_and_compare(vit, change_oracle, wt, root, expect)
+    assert len(got["M"]) + len(got["D"]) + len(got["A"]) >= 500
+    assert "t00/spaces.txt" in got["D"] and "t00/a name with spaces.txt" in got["A"]
 
 
 def test_medium_worktree_skewed_sizes(oracle, tmp_path):

@@ -101,6 +101,73 @@ def test_config4_one_gpus_slice_of_the_mixed_blobs(hasher):
     assert (two == auto).all()
 
 
+def test_config4_whole_ten_million_mixed_blobs(hasher):
+    """BASELINE configs[3] at its full object count: 10,000,000 blobs of lognormal sizes up to 32 MiB, 150 GB, streamed
+    through one GPU from host memory in ten slices of 1,000,000 (slice k+1 is generated while slice k is hashed).  The XOR
+    of all ids equals the fixture's, which libcrypto computed on the CPU (tests/golden/config4.json, slice by slice);
+    2,030 sampled ids against hashlib; the last two slices again through two device queues (the multi-GPU path)."""
+    import json
+    import threading
+    import vit_amd
+    from vit_amd import _abi
+    lib = _abi.load()
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "config4.json")))
+    seed, n_all, slices, clip = gold["seed"], gold["n"], gold["slices"], gold["clip"]
+    per = n_all // slices
+
+    def make(k):
+        rng = np.random.default_rng(seed + 1000 * k)
+        sizes = np.exp(rng.normal(np.log(4500.0), 1.55, per))
+        sizes = np.minimum(sizes * (15000.0 / sizes.mean()), clip).astype(np.uint64)
+        offs = np.zeros(per + 1, dtype=np.uint64)
+        np.cumsum(sizes, out=offs[1:])
+        buf = np.empty(int(offs[-1]) + 1, dtype=np.uint8)
+        assert lib.vit_synth_fill_host(seed, k * per, per, sizes.ctypes.data, offs.ctypes.data, buf.ctypes.data, THREADS) == 0
+        return sizes, offs, buf
+
+    hasher.set_option("host_auto", 1)
+    g0, h0 = hasher.stat("objects_gpu"), hasher.stat("objects_host")
+    acc = np.zeros(20, dtype=np.uint8)
+    payload, checked, hash_s = 0, 0, 0.0
+    nxt = {}
+    cur = make(0)
+    two = vit_amd.Hasher((0, 0))
+    try:
+        for k in range(slices):
+            t = None
+            if k + 1 < slices:
+                t = threading.Thread(target=lambda: nxt.__setitem__("v", make(k + 1)))
+                t.start()
+            sizes, offs, buf = cur
+            ptrs = (offs[:per] + np.uint64(buf.ctypes.data)).astype(np.uint64)
+            dig = hash_ptrs(hasher, ptrs, sizes, per)
+            hash_s += hasher.stat("last_total_ns") / 1e9
+            x = np.bitwise_xor.reduce(dig, axis=0)
+            assert x.tobytes().hex() == gold["per_slice"][k], "slice %d" % k
+            acc ^= x
+            payload += int(offs[-1])
+            mv = memoryview(buf)
+            pick = set(np.random.default_rng(k).integers(0, per, 200).tolist()) | {0, per - 1, int(np.argmax(sizes))}
+            for i in pick:
+                assert dig[i].tobytes() == blob_id(mv[int(offs[i]):int(offs[i + 1])]), (k, i)
+            checked += len(pick)
+            if k >= slices - 2:                                   # the sharded path on the same slices
+                again = hash_ptrs(two, ptrs, sizes, per)
+                assert (again == dig).all(), "two queues, slice %d" % k
+            del mv, buf, ptrs, dig
+            if t is not None:
+                t.join()
+                cur = nxt.pop("v")
+    finally:
+        two.close()
+    assert payload == gold["payload_bytes"] and checked >= 2000
+    assert acc.tobytes().hex() == gold["xor_of_ids"]
+    on_gpu, on_host = hasher.stat("objects_gpu") - g0, hasher.stat("objects_host") - h0
+    assert on_gpu + on_host == n_all and on_gpu > 0.8 * n_all and on_host > 0
+    print("config 4 whole: %.1f GB in %.2f s of hashing = %.1f GB/s; %d objects on the GPU, %d on host threads"
+          % (payload / 1e9, hash_s, payload / hash_s / 1e9, on_gpu, on_host))
+
+
 def test_config5_few_giants_and_a_million_tiny(hasher):
     import vit_amd
     from vit_amd import _abi

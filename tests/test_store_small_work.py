@@ -95,3 +95,44 @@ def test_above_the_bound_a_machine_without_a_gpu_fails_loudly(golden_trees, work
     # and just under the bound it is the host threads' again
     p = vit(wt, "write-tree", "--stats", env={"VIT_HOST_CROSSOVER_BYTES": "5000000", "VIT_HASH_LIBRARY": "/nonexistent/libvit_hash.so"})
     assert p.stdout.decode().strip() == golden_trees["c1_1000x4096"]["root"] and b"(crossover 5000000 bytes" in p.stderr
+
+
+def test_unreadable_file_is_hashed_as_the_empty_blob_by_product_and_oracle(tmp_path):
+    """reference src/commit.cpp:151-153: a regular file that cannot be opened leaves the stringstream empty, and
+    writeTree hashes and stores the empty string for it.  Product and oracle both follow that.  Root opens any file,
+    so under root both run as another user (copies of the program and of the oracle's library in a directory that
+    user can reach)."""
+    import stat
+    import tempfile
+    top = tempfile.mkdtemp(prefix="vit_unreadable_", dir="/tmp")
+    try:
+        os.chmod(top, 0o777)
+        wt = os.path.join(top, "wt")
+        os.makedirs(os.path.join(wt, "d"))
+        open(os.path.join(wt, "d", "secret"), "wb").write(b"cannot be read")
+        open(os.path.join(wt, "plain"), "wb").write(b"plain\n")
+        os.makedirs(os.path.join(wt, ".git", "objects"))
+        exe = shutil.copy(VIT, os.path.join(top, "vit"))
+        lib = shutil.copy(os.path.join(ROOT, "oracle", "liboracle.so"), os.path.join(top, "liboracle.so"))
+        for base, dirs, files in os.walk(top):
+            for x in dirs + files:
+                os.chmod(os.path.join(base, x), 0o777)
+        os.chmod(os.path.join(wt, "d", "secret"), 0)
+        drop = (lambda: os.setuid(65534)) if os.geteuid() == 0 else None
+        env = dict(os.environ, VIT_HASH_LIBRARY="/nonexistent/libvit_hash.so")
+        p = subprocess.run([exe, "write-tree"], cwd=wt, capture_output=True, env=env, preexec_fn=drop, timeout=60)
+        assert p.returncode == 0, p.stderr.decode()
+        code = ("import ctypes as C; L = C.CDLL(%r); out = C.create_string_buffer(20); "
+                "rc = L.vit_oracle_write_tree(b'.', None, out, None, None); print(rc, out.raw.hex())" % lib)
+        q = subprocess.run(["/usr/bin/python3", "-c", code], cwd=wt, capture_output=True, preexec_fn=drop, timeout=60)
+        rc, want = q.stdout.decode().split()
+        assert rc == "0", q.stderr.decode()
+        assert p.stdout.decode().strip() == want
+        # ... and that tree names the empty blob for the file
+        sub = subprocess.run([exe, "ls-tree", want, "-l"], cwd=wt, capture_output=True, env=env).stdout.decode()
+        d_id = [l.split()[2] for l in sub.splitlines() if l.endswith("\td")][0]
+        inner = subprocess.run([exe, "ls-tree", d_id, "-l"], cwd=wt, capture_output=True, env=env).stdout.decode()
+        assert "e69de29bb2d1d6434b8b29ae775ad8c2e48c5391\tsecret" in inner
+        os.chmod(os.path.join(wt, "d", "secret"), stat.S_IRUSR)
+    finally:
+        shutil.rmtree(top, ignore_errors=True)

@@ -52,3 +52,37 @@ def test_static_entry_point_matches_the_allocating_one_twice_in_a_row():
             h._check(h.lib.vit_hash_arena_device_static(h.handle, 0, b["arena"].ptr, b["arena_bytes"], b["offsets"].ptr,
                                                         b["nblocks"].ptr, (1 << 21) + 1, b["digests"].ptr, None))
         assert e.value.code == -4 and "at most" in str(e.value)
+
+
+def test_static_calls_from_two_hashers_on_one_gpu_take_turns():
+    """Every call on a GPU works in that GPU's one scratch array.  Two hashers on the same GPU, driven by two
+    threads at once (the object store itself keeps two hashers per device), must still get their own digests:
+    the library orders the calls with an event per GPU and a lock around wait-launch-record."""
+    import threading
+    import vit_amd
+    rng = np.random.default_rng(33)
+    with vit_amd.Hasher((0,)) as h1, vit_amd.Hasher((0, 0)) as h2:
+        work = []
+        for k, (h, dev) in enumerate(((h1, 0), (h2, 1))):
+            lens = np.minimum(np.exp(rng.normal(np.log(900.0 * (k + 1)), 1.5, 150_000 + 50_000 * k)), 100_000).astype(np.uint64)
+            b = h.synth_arena("blob", 0x5EED0080 + k, 0, len(lens), 0, lens=lens, dev=dev)
+            want = h.hash_device(b).copy()
+            work.append((h, b, want, lens))
+        errors = []
+
+        def run(h, b, want, lens):
+            try:
+                for _ in range(6):
+                    b["digests"].upload(np.zeros(20 * b["n"], dtype=np.uint8))
+                    got = h.hash_device_static(b)
+                    if not (got == want).all():
+                        errors.append("digests differ: %d of %d" % (int((got != want).any(axis=1).sum()), b["n"]))
+            except Exception as e:                                             # a worker must not die silently
+                errors.append(repr(e))
+        threads = [threading.Thread(target=run, args=w) for w in work]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        assert h1.device_status(0) == 0 and h2.device_status(1) == 0

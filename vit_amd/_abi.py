@@ -62,6 +62,7 @@ SIGNATURES = {
     "vit_synth_arena_device": (C.c_int, [vp, C.c_int, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64,
                                         C.c_uint64, vp, vp, vp, vp, C.c_uint64, vp]),
     "vit_synth_bytes": (None, [C.c_uint64, C.c_uint64, vp, C.c_uint64]),
+    "vit_synth_fill_host": (C.c_int, [C.c_uint64, C.c_uint64, C.c_uint64, vp, vp, vp, C.c_int]),
     "vit_time_hash_device": (C.c_int, [vp, C.c_int, vp, C.c_uint64, vp, vp, vp, C.c_uint64, vp,
                                       C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "vit_valu_peak": (C.c_int, [vp, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_float)]),

@@ -58,7 +58,9 @@ std::vector<std::string> worktreeFiles(const std::string& root)
     std::vector<std::string> files;
     std::set<std::string> seen;
     std::error_code ec;
-    fs::recursive_directory_iterator it(root, fs::directory_options::follow_directory_symlink, ec), end;
+    // the reference's iterator has its default options (src/utils/file_utils.cpp:60): a symlink to a directory is not
+    // descended into (and is no regular file, so it is passed over); a symlink to a file counts as the file
+    fs::recursive_directory_iterator it(root, ec), end;
     if (ec) { std::cerr << "Error scanning directory " << root << ": " << ec.message() << '\n'; return files; }
     for (; it != end; it.increment(ec)) {
         if (ec) break;
@@ -88,10 +90,13 @@ ChangeSet detectChanges(ObjectStore& store, const std::string& treeHash, const s
     for (const auto& p : working) all.insert(p);
     out.totalFilesAnalyzed = all.size();
 
-    // One GPU batch over every worktree file (ids only, nothing is stored).
+    // One batch over every worktree file (ids only, nothing is stored).  A file that cannot be opened: the reference's
+    // readFile throws (src/utils/file_utils.cpp:11-15) and its caller records nothing for the path (:94-96).
     std::vector<std::string> contents(working.size());
+    std::vector<bool> unreadable(working.size(), false);
     for (size_t i = 0; i < working.size(); ++i) {
         std::ifstream f(root + '/' + working[i], std::ios::binary);
+        if (!f.is_open()) { unreadable[i] = true; continue; }
         std::ostringstream ss;
         ss << f.rdbuf();
         contents[i] = ss.str();
@@ -101,6 +106,12 @@ ChangeSet detectChanges(ObjectStore& store, const std::string& treeHash, const s
     std::vector<uint8_t> raw;
     if (!view.empty() && !store.hashObjects("blob", view, raw)) { out.ok = false; return out; }
 
+    std::set<std::string> skipped;
+    for (size_t i = 0; i < working.size(); ++i)
+        if (unreadable[i] && committed.count(working[i])) {
+            std::cerr << "Warning: Could not analyze file " << working[i] << ": Failed to open file: " << working[i] << '\n';
+            skipped.insert(working[i]);
+        }
     std::unordered_map<std::string, std::string> now;
     for (size_t i = 0; i < working.size(); ++i) now[working[i]] = hashToHexString(&raw[i * 20]);
 
@@ -109,6 +120,7 @@ ChangeSet detectChanges(ObjectStore& store, const std::string& treeHash, const s
         const auto w = now.find(path);
         if (c == committed.end()) out.changes.push_back({path, ChangeType::ADDED, "", w->second});
         else if (w == now.end()) out.changes.push_back({path, ChangeType::DELETED, c->second, ""});
+        else if (skipped.count(path)) continue;
         else if (c->second != w->second) out.changes.push_back({path, ChangeType::MODIFIED, c->second, w->second});
     }
     return out;

@@ -388,7 +388,12 @@ __device__ __forceinline__ uint32_t physical_simd()
     const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID: SIMD [5:4], CU [11:8], SH [12], SE [15:13]
     const uint32_t xcc = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xFu;
     const uint32_t simd = (hw >> 4) & 3u, cu = (hw >> 8) & 0xFu, sh = (hw >> 12) & 1u, se = (hw >> 13) & 7u;
-    return ((xcc * 8u + se) * 2u + sh) * 64u + cu * 4u + simd;                   // < SCHED_SIMD_KEYS
+    // 8 XCDs x 8 SE x 2 SH x 16 CU x 4 SIMD = SCHED_SIMD_KEYS keys.  The XCC_ID field is four bits wide: a
+    // part that reported an id above 7 would index past the tables, so the key is folded into their size (two
+    // SIMDs would then share an entry, which costs one of them its leader, never a digest).
+    static_assert(SCHED_SIMD_KEYS == 8u * 8u * 2u * 16u * 4u && (SCHED_SIMD_KEYS & (SCHED_SIMD_KEYS - 1u)) == 0u,
+                  "the key's fields and the size of SchedState's tables belong together");
+    return (((xcc * 8u + se) * 2u + sh) * 64u + cu * 4u + simd) & (SCHED_SIMD_KEYS - 1u);
 }
 
 __device__ __forceinline__ uint32_t peek(const uint32_t* p)

@@ -676,7 +676,9 @@ WorkPool::Ticket ObjectStore::storeAsync(const std::string& type, const std::vec
     const uint8_t* r = raw.data();
     const int level = deflate_level_;
     const uint64_t dirs_generation = store_calls_;        // handles are good for one top-level call: between calls the directories may have been replaced
-    return pool().submit(WorkPool::LOW, slices, [this, type, c, r, n, slices, level, dz, dirs_generation, &outcome](size_t s) {
+    const char* bt = std::getenv("VIT_DEBUG_BAD_TRAILER");
+    const size_t bad_trailer_every = bt ? size_t(std::strtoull(bt, nullptr, 10)) : 0;
+    return pool().submit(WorkPool::LOW, slices, [this, type, c, r, n, slices, level, dz, dirs_generation, bad_trailer_every, &outcome](size_t s) {
         for (size_t i = n * s / slices; i < n * (s + 1) / slices; ++i) {
             try {
                 FanoutDirs& dirs = threadDirs();
@@ -717,6 +719,7 @@ WorkPool::Ticket ObjectStore::storeAsync(const std::string& type, const std::vec
                         ad = adler32(ad, reinterpret_cast<const Bytef*>(c[i].data() + done), uInt(take));
                         done += take;
                     }
+                    if (bad_trailer_every && i % bad_trailer_every == 0) ad ^= 1;        // tests: as if the stream's trailer were wrong
                     const bool sane = zn >= 8 && zn <= compressBound(uLong(size_t(hl) + c[i].size())) && z[0] == 0x78 && z[1] == 0x9c &&
                                       ((uint32_t(z[zn - 4]) << 24) | (uint32_t(z[zn - 3]) << 16) | (uint32_t(z[zn - 2]) << 8) | z[zn - 1]) == uint32_t(ad);
                     if (sane) { put(reinterpret_cast<const char*>(z), zn); continue; }

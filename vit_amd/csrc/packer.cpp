@@ -324,4 +324,19 @@ void vit_synth_bytes(uint64_t seed, uint64_t index, uint8_t* dst, uint64_t len)
     }
 }
 
+
+int vit_synth_fill_host(uint64_t seed, uint64_t first_index, uint64_t n, const uint64_t* lens, const uint64_t* offsets,
+                        uint8_t* dst, int threads)
+{
+    if (n && (!lens || !offsets || !dst)) return VIT_ERR_ARG;
+    try {
+        std::vector<uint64_t> prefix(n + 1, 0);
+        for (uint64_t i = 0; i < n; ++i) prefix[i + 1] = prefix[i] + lens[i] + 64;      // weight: bytes, and a little per object
+        vit::parallel_ranges(n, threads < 1 ? 1 : threads, prefix.data(), [&](int, uint64_t b, uint64_t e) {
+            for (uint64_t i = b; i < e; ++i) vit_synth_bytes(seed, first_index + i, dst + offsets[i], lens[i]);
+        });
+        return VIT_OK;
+    } catch (const std::exception&) { return VIT_ERR_NOMEM; }
+}
+
 }  // extern "C"

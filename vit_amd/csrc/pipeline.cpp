@@ -162,9 +162,14 @@ hipError_t launch_hash(vit_hasher* h, Queue& q, const vit::DeviceBatch& b, hipSt
 
 // Collect a finished chunk: wait for it, scatter its digests to the caller and
 // note the status word it brought back.
-int retire(Queue& q, Staging& s, uint8_t* digests)
+// While the chunk is not done, the waiting thread works through tasks of `help` (short host-lane tasks of
+// the same call, when there are any) instead of sleeping: the threads that drive the queues count against
+// the call's thread budget, and with eight queues they would otherwise be half of it, asleep.
+int retire(Queue& q, Staging& s, uint8_t* digests, WorkPool* pool = nullptr, const WorkPool::Ticket* help = nullptr)
 {
     if (!s.in_flight) return VIT_OK;
+    if (pool && help && *help)
+        while (hipEventQuery(s.done) == hipErrorNotReady && pool->help(*help)) {}
     HIP_TRYQ(q, hipEventSynchronize(s.done));
     if (s.obj.empty()) std::memcpy(digests + s.first * 20, s.h_dig, s.count * 20);
     else for (size_t i = 0; i < s.obj.size(); ++i) std::memcpy(digests + s.obj[i] * 20, s.h_dig + i * 20, 20);
@@ -206,6 +211,7 @@ struct Job {
     const uint8_t* const* data; const uint64_t* len;
     const uint32_t* nb;                    // block count per object (all objects)
     uint8_t* digests;
+    const WorkPool::Ticket* help;          // host-lane tasks short enough for a thread that waits on a chunk (or null)
 };
 
 // Queue copy, kernel, digest and status read-back of a chunk whose arena bytes
@@ -237,7 +243,7 @@ int submit_chunk(Queue& q, const Job& job, Staging& s, hipStream_t stream, const
 {
     vit_hasher* h = job.h;
     const double begin_ms = double(ns_since(q.trace_t0)) * 1e-6;
-    int rc = retire(q, s, job.digests);
+    int rc = retire(q, s, job.digests, h->pool.get(), job.help);
     if (rc) return rc;
     if (h->opt.fail_at_chunk && ++q.chunks_this_call == h->opt.fail_at_chunk) {
         q.err = "failure injected at chunk " + std::to_string(q.chunks_this_call) + " (option debug_fail_at_chunk)";
@@ -358,7 +364,7 @@ int run_queue_body(Queue& q, const Job& job, const std::vector<uint64_t>& mine, 
     while (next_long < longs.size())
         if ((rc = submit_long())) return rc;
     for (Staging& s : q.st)
-        if ((rc = retire(q, s, job.digests))) return rc;
+        if ((rc = retire(q, s, job.digests, h->pool.get(), job.help))) return rc;
     return VIT_OK;
 }
 
@@ -518,13 +524,14 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
     // priority, beside the GPU batch; longest first, so the tail is short.
     std::vector<uint32_t> host_group;                     // group g = host_idx[host_group[g] .. host_group[g+1]): streams run side by side
     std::vector<uint32_t> host_task;                      // pool task t = groups [host_task[t], host_task[t+1])
-    vit::WorkPool::Ticket host_work;
+    std::function<void(size_t)> run_host_task;
+    vit::WorkPool::Ticket host_work, host_work_short;
     // From the submit below on, the pool's workers hold references into this
     // frame: every path out waits for them first.
     struct WaitHost {
-        vit::WorkPool& pool; vit::WorkPool::Ticket& t;
-        ~WaitHost() { if (t) pool.wait(t); }
-    } wait_host{*h->pool, host_work};
+        vit::WorkPool& pool; vit::WorkPool::Ticket& a; vit::WorkPool::Ticket& b;
+        ~WaitHost() { if (a) pool.wait(a); if (b) pool.wait(b); }
+    } wait_host{*h->pool, host_work, host_work_short};
     // A core gets through more bytes with several objects' streams interleaved
     // (sha1_host.h), where the machine's SHA instructions are pipelined: when the
     // objects outnumber the threads, the objects after the longest few go in
@@ -555,7 +562,13 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
             for (uint32_t k = host_group[g]; k < host_group[g + 1]; ++k) acc += len[host_idx[k]];
             if (acc >= kHostTaskBytes || g + 2 == host_group.size()) { host_task.push_back(uint32_t(g + 1)); acc = 0; }
         }
-        host_work = h->pool->submit(vit::WorkPool::LOW, host_task.size() - 1, [&](size_t t) {
+        // Two groups of tasks, both for the pool's workers, the second also for threads that wait on a device
+        // chunk (retire): the tasks of objects long enough to keep such a thread from its queue for milliseconds
+        // (host_idx is longest first, so they are the leading ones) stay with the workers alone.
+        constexpr uint64_t kHelpMaxBytes = 4u << 20;
+        size_t long_tasks = 0;
+        while (long_tasks + 1 < host_task.size() && len[host_idx[host_group[host_task[long_tasks]]]] > kHelpMaxBytes) ++long_tasks;
+        run_host_task = [&, h, t0](size_t t) {
             struct Stamp {                                // the latest finish over all tasks
                 vit_hasher* h; clk::time_point t0;
                 ~Stamp() { const uint64_t now = ns_since(t0); uint64_t cur = h->last.host_done_ns.load();
@@ -571,12 +584,15 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
                 vit::host_object_ids(type, ptr, ln, cnt, out);
                 for (size_t j = 0; j < cnt; ++j) std::memcpy(digests + host_idx[b + j] * 20, out + 20 * j, 20);
             }
-        });
+        };
+        const size_t all_tasks = host_task.size() - 1;
+        host_work = h->pool->submit(vit::WorkPool::LOW, long_tasks, [&](size_t t) { run_host_task(t); });
+        host_work_short = h->pool->submit(vit::WorkPool::LOW, all_tasks - long_tasks, [&, long_tasks](size_t t) { run_host_task(long_tasks + t); });
         h->count.objects_host += host_idx.size();
         h->count.bytes_host += host_bytes;
     }
 
-    Job job{h, type, tl, data, len, nb.data(), digests};
+    Job job{h, type, tl, data, len, nb.data(), digests, &host_work_short};
     std::vector<std::vector<uint64_t>> parts;
     shard(gpu_idx, nb.data(), h->queues.size(), parts);
     std::vector<int> rcs(h->queues.size(), VIT_OK);
@@ -592,7 +608,9 @@ static int hash_batch(vit_hasher* h, const char* type, uint32_t tl, const uint8_
     }
     h->last.gpu_done_ns = ns_since(t0);
     h->pool->wait(host_work);
+    h->pool->wait(host_work_short);
     host_work.reset();
+    host_work_short.reset();
     h->last.pack_ns = 0;
     for (uint64_t p : pack_ns) h->last.pack_ns = std::max(h->last.pack_ns, p);
     vit::learn_from_call(h, len, gpu_idx, host_idx.size());

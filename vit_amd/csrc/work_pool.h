@@ -108,6 +108,22 @@ public:
         g->finished.wait(lk, [&] { return g->done == g->n; });
     }
 
+    // Run ONE unclaimed task of the group on the calling thread, if it has any left.  For a thread that
+    // has something else to wait for (a device event) and would rather work than sleep meanwhile.
+    bool help(const Ticket& g)
+    {
+        if (!g || g->n == 0) return false;
+        std::unique_lock<std::mutex> lk(m_);
+        if (g->next >= g->n) return false;
+        const size_t i = g->next++;
+        if (g->next == g->n) drop(g);
+        lk.unlock();
+        g->fn(i);
+        lk.lock();
+        if (++g->done == g->n) g->finished.notify_all();
+        return true;
+    }
+
     // submit + wait.
     void run(Priority prio, size_t n, std::function<void(size_t)> fn, int node = -1) { wait(submit(prio, n, std::move(fn), node)); }
 

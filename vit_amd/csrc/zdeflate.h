@@ -18,6 +18,40 @@
 // Scope: inputs of at most 65536 bytes (framed), for which zlib's 64 KiB window never slides;
 // longer objects stay with the host library.  Compiles as plain C++ for the host tests and as
 // device code under hipcc (ZD_FN).
+//
+// Which zlib: 1.2.11's deflate.  A host whose libz deflates differently (another version's
+// tuning, zlib-ng behind the zlib interface) would give other bytes for the same object; the
+// object store compares the first device-made batch with the linked library and leaves the
+// work to that library when they differ (object_store.cpp).
+//
+// This file is written after the algorithm of the zlib library, whose notice follows:
+//
+//   zlib.h -- interface of the 'zlib' general purpose compression library
+//   version 1.2.11, January 15th, 2017
+//
+//   Copyright (C) 1995-2017 Jean-loup Gailly and Mark Adler
+//
+//   This software is provided 'as-is', without any express or implied
+//   warranty.  In no event will the authors be held liable for any damages
+//   arising from the use of this software.
+//
+//   Permission is granted to anyone to use this software for any purpose,
+//   including commercial applications, and to alter it and redistribute it
+//   freely, subject to the following restrictions:
+//
+//   1. The origin of this software must not be misrepresented; you must not
+//      claim that you wrote the original software. If you use this software
+//      in a product, an acknowledgment in the product documentation would be
+//      appreciated but is not required.
+//   2. Altered source versions must be plainly marked as such, and must not be
+//      misrepresented as being the original software.
+//   3. This notice may not be removed or altered from any source distribution.
+//
+//   Jean-loup Gailly        Mark Adler
+//   jloup@gzip.org          madler@alumni.caltech.edu
+//
+// (This is an altered restatement, not the original software: restructured for one object per
+// GPU lane as described above.)
 #pragma once
 #include <stdint.h>
 
