@@ -251,22 +251,27 @@ int vit_bin_order_device(vit_hasher *h, int dev, const uint32_t *d_nblocks, uint
 
 /* The zlib stream of every object of a device-resident arena: the bytes the
  * reference stores, compress(header + content) at the default level
- * (src/commit.cpp:98-105), made by one GPU lane per object with the zlib library's
- * own choices, so that the files are identical to the reference's.  Object i's
- * stream is written to d_out + d_out_offsets[i], where the caller has left room
- * for vit_deflate_bound(framed length) bytes, and its length to d_out_lens[i].
+ * (src/commit.cpp:98-105), with the zlib library's own choices, so that the files
+ * are identical to the reference's.  Object i's stream is written to
+ * d_out + d_out_offsets[i], where the caller has left room for
+ * vit_deflate_bound(framed length) bytes, and its length to d_out_lens[i].
  * A length of 0 means the object was not done here and is the host's to deflate:
- * its framed length (header + content) exceeds 65536 bytes, the range in which
- * zlib's window never slides, or its slot was bad (status word, as for the
- * hashing launches).  The arena is the one the hashing entry points take (message
- * words as native dwords, padded blocks); all pointers are device pointers on
- * queue `dev`; asynchronous on `stream` (NULL = the queue's own).  d_order (optional,
- * as for vit_hash_arena_device: object indices by length, vit_bin_order) lets the 64
- * lanes of a wave take objects of similar length, which end together.  On first use the
- * library allocates 181 KiB of device memory per object in flight (option
- * "deflate_lanes", default 65536: 11.9 GB) and keeps it with the queue; launches
- * on one queue share it, so the library makes each wait for the one before it,
- * whatever streams they are on. */
+ * its framed length (header + content) exceeds option "deflate_max_bytes", or its
+ * slot was bad (status word, as for the hashing launches).  The arena is the one
+ * the hashing entry points take (message words as native dwords, padded blocks);
+ * all pointers are device pointers on queue `dev`; asynchronous on `stream`
+ * (NULL = the queue's own).  d_order (optional, as for vit_hash_arena_device:
+ * object indices by length, vit_bin_order) evens out the launches' tails.
+ * Two kernels share the work.  An object of up to 16382 framed bytes (one deflate
+ * block; the default "deflate_max_bytes") is deflated by one WAVE whose 64 lanes
+ * build its hash chains, search them and code its symbols together, with every
+ * table in LDS: device memory sees the object once and its stream once, and no
+ * workspace exists.  With "deflate_max_bytes" raised (at most 65536, the range in
+ * which zlib's window never slides) the longer objects are deflated one per LANE
+ * with 181 KiB of tables each in device memory, which the library then allocates
+ * for "deflate_lanes" objects in flight (default 4096: 0.74 GB) and keeps with
+ * the queue.  Launches on one queue that may use those tables are made to wait
+ * for one another, whatever streams they are on. */
 int vit_deflate_arena_device(vit_hasher *h, int dev, const void *d_arena, uint64_t arena_bytes,
                              const uint64_t *d_offsets, const uint32_t *d_nblocks,
                              const uint32_t *d_order, uint64_t n,
@@ -275,12 +280,10 @@ int vit_deflate_arena_device(vit_hasher *h, int dev, const void *d_arena, uint64
 
 /* The same for objects in host memory (pack, copy, kernel, copy back, chunk by
  * chunk, on the hasher's first device queue).  Objects whose framed length exceeds
- * option "deflate_max_bytes" (default 16384, at most 65536) are not done here: one
- * lane gets through about 0.1 MB of input per second, so the device is for the many
- * small objects of a batch and host cores for its long ones.  out: host memory of at
- * least vit_deflate_out_bytes() bytes, best pinned (vit_arena_alloc).  On return
- * stream i is out[out_off[i] .. out_off[i] + out_len[i]); out_len[i] = 0 means the
- * object is the caller's to deflate. */
+ * option "deflate_max_bytes" (default 16382, at most 65536) are not done here.
+ * out: host memory of at least vit_deflate_out_bytes() bytes, best pinned
+ * (vit_arena_alloc).  On return stream i is out[out_off[i] .. out_off[i] +
+ * out_len[i]); out_len[i] = 0 means the object is the caller's to deflate. */
 int vit_deflate_objects(vit_hasher *h, const char *type, const uint8_t *const *data,
                         const uint64_t *len, uint64_t n, uint8_t *out, uint64_t out_cap,
                         uint64_t *out_off, uint32_t *out_len);

@@ -47,7 +47,7 @@ def hasher(_session_hasher):
     h = _session_hasher
     for name, value in (("kernel", 0), ("chunk_bytes", 64 << 20), ("chunk_object_multiple", 8192), ("trace", 0),
                         ("host_threshold_bytes", 0), ("host_auto", 1), ("sched_waves", 1), ("sched_min_groups", 4096), ("sched_tail_percent", 75),
-                        ("debug_fail_at_chunk", 0), ("lane_rate", 0), ("core_rate", 0), ("core_rate_multi", 0), ("host_bias_percent", 100), ("deflate_max_bytes", 16384), ("host_min_bytes", 16 << 10), ("copy_rate", 0), ("pack_rate", 0)):
+                        ("debug_fail_at_chunk", 0), ("lane_rate", 0), ("core_rate", 0), ("core_rate_multi", 0), ("host_bias_percent", 100), ("deflate_max_bytes", 16382), ("host_min_bytes", 16 << 10), ("copy_rate", 0), ("pack_rate", 0)):
         h.set_option(name, value)
     return h
 

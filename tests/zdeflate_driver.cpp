@@ -1,8 +1,11 @@
 // The deflate restatement of vit_amd/csrc/zdeflate.h against the zlib library itself (compress2 at the default
 // level, which is what the reference's compress() call at src/commit.cpp:100 runs): random, text-like, constant,
 // long-distance and short-distance repetitive inputs of every size up to the 64 KiB the restatement covers, byte
-// for byte.  Built and run by tests/test_zdeflate.py:  zdeflate_driver <inputs> <seed>
+// for byte.  Inputs of up to 16,382 bytes (one block) also go through zwave.h's emulation of the wave-per-object formulation (chains
+// in a bucket table, two precomputed search answers per position, the decision loop over them, symbols coded by lanes).
+// Built and run by tests/test_zdeflate.py:  zdeflate_driver <inputs> <seed> [wave-only]
 #include "zdeflate.h"
+#include "zwave.h"
 #include <zlib.h>
 #include <cstdio>
 #include <cstring>
@@ -18,6 +21,8 @@ struct PtrIn {
 };
 int main(int argc, char** argv) {
     int rounds = argc > 1 ? atoi(argv[1]) : 2000;
+    const bool wave_only = argc > 3;                            // smaller inputs, the wave formulation alone: many more of them per second
+    int waved = 0;
     zd::Tables t; zd::make_tables(t);
     for (uint32_t lc = 0; lc < 256; ++lc) if (zd::length_code_of(lc) != t.length_code[lc]) { printf("length_code_of(%u)\n", lc); return 3; }
     for (uint32_t d = 0; d < 32768; ++d) if (zd::dist_code_of(d) != (d < 256 ? t.dist_code[d] : t.dist_code[256 + (d >> 7)])) { printf("dist_code_of(%u)\n", d); return 3; }
@@ -33,6 +38,7 @@ int main(int argc, char** argv) {
         uint32_t n;
         switch (rng() % 8) { case 0: n = rng() % 40; break; case 1: n = rng() % 700; break; case 2: n = 4000 + rng() % 300; break;
             case 3: n = 16000 + rng() % 1000; break; case 4: n = 32700 + rng() % 200; break; case 5: n = 65536 - rng() % 3; break; default: n = rng() % 65537; }
+        if (wave_only) { switch (rng() % 7) { case 0: n = rng() % 64; break; case 1: n = 4000 + rng() % 700; break; case 2: n = 9000 + rng() % 300; break; case 3: n = zw::kMaxInput - rng() % 40; break; default: n = rng() % 9300; } }
         std::vector<uint8_t> in(n + 1);
         int kind = rng() % 7;
         if (kind == 0) for (auto& b : in) b = uint8_t(rng());
@@ -42,11 +48,26 @@ int main(int argc, char** argv) {
         else if (kind == 4) { for (size_t k = 0; k < n; ++k) in[k] = (k >= 5000 && rng() % 10) ? in[k - 5000 + (rng() % 3 == 0)] : uint8_t(rng()); }
         else if (kind == 5) { for (size_t k = 0; k < n; ++k) in[k] = (k >= 40 && rng() % 50) ? in[k - 1 - rng() % 40] : uint8_t(rng() % 7); }
         else { for (size_t k = 0; k < n; ++k) in[k] = uint8_t((k * 7 + (k >> 8)) ^ (rng() % 64 == 0 ? rng() : 0)); }
+        if (rng() % 3 == 0 && n > 40) {                          // a tail of zeros or of a repeated pattern: matches that run into the end of the input
+            const size_t tail = 1 + rng() % 40;
+            for (size_t k = n - tail; k < n; ++k) in[k] = rng() % 2 ? 0 : in[k - 1 - rng() % 3];
+        }
         uLongf zl = compressBound(n);
         std::vector<uint8_t> z(zl);
         if (compress2(z.data(), &zl, in.data(), n, 6) != Z_OK) { puts("zlib failed"); return 2; }
-        std::fill(head.begin(), head.end(), 0);
         std::vector<uint8_t> out(zd::bound(n));
+        if (n <= zw::kMaxInput) {
+            std::vector<uint8_t> wo(zd::bound(n));
+            const uint32_t wg = zw::deflate_emulated(&t, PtrIn{in.data(), n}, n, wo.data(), uint32_t(wo.size()));
+            ++waved;
+            if (wg != zl || memcmp(wo.data(), z.data(), zl)) {
+                size_t k = 0; while (k < wg && k < zl && wo[k] == z[k]) ++k;
+                printf("WAVE MISMATCH round %d kind %d n %u: got %u bytes, zlib %lu, first difference at %zu\n", r, kind, n, wg, (unsigned long)zl, k);
+                if (++bad > 5) return 1;
+            }
+        }
+        if (wave_only) { total += n; continue; }
+        std::fill(head.begin(), head.end(), 0);
         const uint32_t st = r % 2 ? 3 : 1;                     // the arrays strided as the GPU lanes interleave theirs, and plain
         zd::Work w{{head.data(), st}, {prev.data(), st}, {dbuf.data(), st}, {lbuf.data(), st}, small.data() + (r % 3), heap.data() + (r % 4), uint32_t(r % 2 ? 5 : 1), out.data(), uint32_t(out.size())};
         d.in = PtrIn{in.data(), n};
@@ -58,6 +79,6 @@ int main(int argc, char** argv) {
             if (++bad > 5) return 1;
         }
     }
-    printf("%d inputs, %zu bytes, %d mismatches\n", rounds, total, bad);
+    printf("%d inputs (%d also through the wave formulation), %zu bytes, %d mismatches\n", rounds, waved, total, bad);
     return bad != 0;
 }

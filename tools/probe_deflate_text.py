@@ -18,6 +18,8 @@ starts = rng.integers(0, len(text) - L, n)
 blobs = [text[int(s):int(s) + L] for s in starts]
 h = vit_amd.Hasher((0,))
 h.set_option("deflate_max_bytes", 65536)
+if os.environ.get("VIT_DEFLATE_CHUNK"):
+    h.set_option("deflate_chunk_bytes", int(os.environ["VIT_DEFLATE_CHUNK"]))
 if os.environ.get("VIT_DEFLATE_LANES"):
     h.set_option("deflate_lanes", int(os.environ["VIT_DEFLATE_LANES"]))
 got, dt = h.deflate_objects("blob", blobs)      # first call allocates

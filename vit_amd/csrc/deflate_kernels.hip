@@ -17,6 +17,7 @@
 // content, whose positions have hash chains to walk, at about four times that.
 #include "kernels.h"
 #include "zdeflate.h"
+#include "zwave.h"
 
 namespace vit {
 
@@ -43,7 +44,7 @@ struct ArenaBytes {
 
 // (The register allocator takes every register it may for this much inlined code: one wave per SIMD, 65536 lanes
 // on the chip, whatever occupancy is asked for; more lanes would only wait on the same memory system.)
-__global__ __launch_bounds__(64) void deflate_kernel(DeflateBatch b)
+__global__ __launch_bounds__(64) void deflate_kernel(DeflateBatch b, uint32_t only_above)
 {
     const uint32_t lane = threadIdx.x;
     // One workspace per wave; in every table of it the 64 lanes' entries are interleaved (entry e of
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(DeflateBatch b)
             const uint32_t* last = reinterpret_cast<const uint32_t*>(b.arena + off + (uint64_t)(nb - 1u) * 64u);
             n = (((uint64_t)last[14] << 32) | last[15]) >> 3;
             if (n > (uint64_t)zd::kMaxInput || n + 9u > (uint64_t)nb * 64u) { b.out_len[i] = 0; mine = false; }   // the host's share
+            else if (n <= only_above || n > b.max_input) mine = false;      // a wave kernel's object, or the host's
         }
         if (mine) {
             w.out = b.out + b.out_off[i];
@@ -103,22 +105,451 @@ __global__ __launch_bounds__(64) void deflate_kernel(DeflateBatch b)
     }
 }
 
+
+// ---- One object per WORKGROUP of four waves, its tables in LDS (zwave.h) ---------------------------------------------
+//
+// The lane kernel above keeps 181 KiB of tables per object in device memory and is bound by their scattered traffic
+// (277 bytes over the fabric per input byte, waves issuing in 7 % of their cycles).  For objects of up to 16382 bytes
+// (one deflate block) the tables shrink to a few times the object (bucket table, chain entries, the block's symbols)
+// and fit a workgroup's share of LDS.  Per object: the message is loaded into LDS; one wave builds the hash chains 64
+// positions at a time; then, 256 positions at a time, every thread searches one position's chain and one wave runs
+// zlib's decisions over the answers; the block's symbols and their counts go to a slot of the workgroup's scratch in
+// device memory.  After kGroup objects the first kGroup threads write one object's block each (trees, codes, bits,
+// checksum: zdeflate.h's own code, the stream straight to its place): a Huffman tree is a serial chain of dependent
+// accesses that lanes cannot share but can each have one of.  Device memory sees the object once, its symbols out
+// and in, and its stream once.  Four size classes (LDS per workgroup, workgroups per CU): up to 1536 bytes (16 KiB, 8),
+// 4608 (33 KiB, 4), 9216 (63 KiB, 2), 16382 (117 KiB, 1); every class is one launch over the batch, each workgroup
+// taking the objects of its class.
+constexpr uint32_t kGroup = 32;                              // objects a workgroup scans before it writes their blocks
+constexpr uint32_t kScanTile = 512;                         // positions searched while the 512 before are decided over
+constexpr uint32_t kRefill = 16;                            // searching lanes that must be free before the wave stops to hand out positions
+constexpr uint32_t kHopsInARow = 2;                         // chain entries a lane looks at between two comparisons
+
+template <int NMAX, int BKBITS> struct WaveShared {
+    uint32_t data[(NMAX + zw::kPad + 8) / 4];               // the framed message, byte i at byte i, zeros behind it
+    union {
+        uint16_t bucket[1 << BKBITS];                       // while the chains are built
+        struct { uint16_t d_buf[NMAX + 2]; uint8_t l_buf[NMAX + 2]; } sym;   // then the block's symbols
+    } a;
+    uint16_t entry[NMAX + 64];                              // the chains (zw::Chain)
+    zw::Found found[2][kScanTile];                          // the searches' answers for the positions of two tiles
+    uint32_t grab[2];                                       // per tile: how many of its positions have been handed out
+    uint16_t lt_fc[zd::kLCodes + 2], dt_fc[zd::kDCodes + 2];   // the symbols' counts
+    uint32_t n_sym;                                         // the scan's symbols, for the waves that do not run it
+    uint32_t elect;                                         // which wave runs the serial parts
+    uint32_t sum_a;                                         // the checksum's two sums before their reduction
+    unsigned long long sum_b;
+};
+
+// A workgroup's scratch in device memory: kGroup slots of symbols, the kGroup objects' tree arrays interleaved
+// (entry e of slot s at e * kGroup + s: the lanes that build the trees read the same entry of their own arrays
+// together), and a few words per slot.
+template <int NMAX> struct WaveScratch {
+    static constexpr uint64_t kSymBytes = (3ull * (NMAX + 2) + 15) / 16 * 16;
+    static constexpr uint64_t kSmallBytes = 2ull * zd::kSmallEntries * kGroup, kHeapBytes = 4ull * zd::kHeapEntries * kGroup;
+    static constexpr uint32_t kMetaWords = 8;                // per slot: object (2), length, symbols, checksum, where a stored block's bytes go
+    static constexpr uint64_t kMetaBytes = 4ull * kMetaWords * kGroup;
+    static constexpr uint64_t kBytes = (kGroup * kSymBytes + kSmallBytes + kHeapBytes + kMetaBytes + 255) / 256 * 256;
+};
+
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint32_t lane_value(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)uniform(lane)); }
+__device__ __forceinline__ void lds_settled() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }   // within a wave: earlier LDS writes before later reads
+
+// ++ of a 16-bit counter in LDS by any number of lanes at once (the counters lie in pairs in a dword).
+__device__ __forceinline__ void bump_lds(uint16_t* e)
+{
+    const uintptr_t at = reinterpret_cast<uintptr_t>(e);
+    __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(at & ~uintptr_t(3)), (at & 2u) ? 0x10000u : 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// One object's block by one lane: the trees from the symbols' counts, the block's head and its codes (zdeflate.h's code
+// as it is), the checksum the scan worked out.  A block that zlib stores is left to the caller: meta[5] = where its
+// bytes go.  Not inlined: its registers are its own, the scan's loops keep theirs.
+template <int NMAX>
+__device__ __attribute__((noinline)) void write_block_by_lane(const DeflateBatch& b, const zd::Tables* tables, uint8_t* sym, uint16_t* small,
+                                                              uint32_t* heap, uint32_t* meta)
+{
+    const uint64_t i = ((uint64_t)meta[1] << 32) | meta[0];
+    const uint32_t n = meta[2], adler = meta[4];
+    zd::Deflater<ArenaBytes> df;
+    df.in = ArenaBytes{b.arena + b.offsets[i]};
+    zd::Work w;
+    w.head = zd::Arr16{nullptr, 1}; w.prev = zd::Arr16{nullptr, 1};
+    w.d_buf = zd::Arr16{reinterpret_cast<uint16_t*>(sym), 1};
+    w.l_buf = zd::Arr8{sym + 2u * (NMAX + 2), 1};
+    w.small = small; w.heap = heap; w.small_stride = kGroup;
+    w.out = b.out + b.out_off[i];
+    w.out_cap = zd::bound(n);
+    df.setup(tables, w, n);
+    df.put_byte(0x78); df.put_byte(0x9c);
+    df.s.last_lit = meta[3];
+    const int kind = df.plan_block(n);
+    df.emit_block_head(kind, n, 1);
+    uint32_t stored_at = 0;
+    if (kind == zd::Deflater<ArenaBytes>::kStored) { stored_at = df.s.pending; df.s.pending += n; if (df.s.pending > w.out_cap) df.s.overflow = true; }
+    else { df.compress_block(kind == zd::Deflater<ArenaBytes>::kFixed); df.bi_windup(); }
+    df.put_byte(adler >> 24); df.put_byte((adler >> 16) & 0xffu); df.put_byte((adler >> 8) & 0xffu); df.put_byte(adler & 0xffu);
+    b.out_len[i] = df.s.overflow ? 0u : df.s.pending;
+    meta[5] = df.s.overflow ? 0u : stored_at;
+}
+
+template <int NMAX, int BKBITS, int POSBITS>
+__global__ __launch_bounds__(256, 4) void deflate_wave_kernel(DeflateBatch b, uint32_t n_above)
+{
+    __shared__ WaveShared<NMAX, BKBITS> sh;
+    using Scratch = WaveScratch<NMAX>;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const zd::Tables* const tables = static_cast<const zd::Tables*>(b.tables_raw);
+    uint8_t* const scratch = b.workspace + (uint64_t)blockIdx.x * Scratch::kBytes;
+    uint16_t* const g_small = reinterpret_cast<uint16_t*>(scratch + kGroup * Scratch::kSymBytes);
+    uint32_t* const g_heap = reinterpret_cast<uint32_t*>(scratch + kGroup * Scratch::kSymBytes + Scratch::kSmallBytes);
+    uint32_t* const g_meta = reinterpret_cast<uint32_t*>(scratch + kGroup * Scratch::kSymBytes + Scratch::kSmallBytes + Scratch::kHeapBytes);
+    const zw::Chain chain{sh.entry, BKBITS, POSBITS};
+    constexpr uint32_t kBuckets = 1u << BKBITS;
+    uint64_t spent[8] = {0, 0, 0, 0, 0, 0, 0, 0};           // diagnostics: cycles by phase (DeflateBatch::trace)
+    uint64_t mark = __builtin_readcyclecounter();
+    auto lap = [&](int phase) { const uint64_t now = __builtin_readcyclecounter(); spent[phase] += now - mark; mark = now; };
+
+    // One wave of the four runs what is serial (the chains, the decisions, the group's blocks).  A CU holds several
+    // workgroups and gives each of them one wave on every SIMD, in the same wave slot: the wave whose SIMD number is
+    // its slot's (mod 4) is the serial one, so that the workgroups of a CU have theirs on different SIMDs.  (Where
+    // waves land is the hardware's to say: the election below yields exactly one wave whatever it says.)
+    if (tid == 0) sh.elect = ~0u;
+    __syncthreads();
+    {
+        const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID: wave slot [3:0], SIMD [5:4]
+        if (lane == 0) atomicMin(&sh.elect, ((((hw >> 4) - hw) & 3u) << 2) | wave);
+    }
+    __syncthreads();
+    const uint32_t serial_wave = sh.elect & 3u;
+    const bool serial = wave == serial_wave;
+
+    // One lane per object of the group: the trees, the block's head and its codes, zdeflate.h's code as it is.  A block
+    // that zlib stores (content no code shortens) has its bytes copied by all threads afterwards.
+    constexpr uint32_t kMeta = Scratch::kMetaWords;
+    auto write_blocks = [&](uint32_t count) {
+        __syncthreads();
+        if (serial && lane < count)
+            write_block_by_lane<NMAX>(b, tables, scratch + (uint64_t)lane * Scratch::kSymBytes, g_small + lane, g_heap + lane, g_meta + lane * kMeta);
+        __syncthreads();
+        lap(5);
+        for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t* const meta = g_meta + k * kMeta;
+            const uint32_t stored_at = meta[5];
+            if (stored_at == 0) continue;
+            const uint64_t i = ((uint64_t)meta[1] << 32) | meta[0];
+            const uint32_t n = meta[2];
+            const uint8_t* const from = b.arena + b.offsets[i];
+            uint8_t* const to = b.out + b.out_off[i] + stored_at;
+            for (uint32_t j = tid; j < n; j += 256u) to[j] = from[j ^ 3u];
+        }
+        __syncthreads();
+        lap(6);
+    };
+
+    uint32_t in_group = 0;
+    for (uint64_t slot = blockIdx.x; slot < b.n; slot += gridDim.x) {
+        // which object, and is it this launch's (everything here is the same in all threads)
+        uint64_t i = slot;
+        if (b.order) { i = b.order[slot]; if (i >= b.n) { if (tid == 0 && NMAX == 1536) atomicOr(b.status, STATUS_BAD_ORDER); continue; } }
+        const uint64_t off = b.offsets[i];
+        const uint32_t nb = b.nblocks[i];
+        uint32_t bad = 0;
+        if (off & 15u) bad |= STATUS_MISALIGNED;
+        if (off > b.arena_bytes || (uint64_t)nb * 64u > b.arena_bytes - off) bad |= STATUS_OUT_OF_BOUNDS;
+        if (bad || nb == 0) {                               // flagged once, by the first class's launch
+            if (tid == 0 && NMAX == 1536) { if (bad) atomicOr(b.status, bad); b.out_len[i] = 0; }
+            continue;
+        }
+        if ((uint64_t)nb * 64u > (uint64_t)NMAX + 9u + 63u) continue;         // too long for this class, whatever its padding says
+        const uint32_t* const src = reinterpret_cast<const uint32_t*>(b.arena + off);
+        // the framed length is in the padding: the last two dwords of the last block hold it in bits
+        const uint64_t bits = ((uint64_t)src[(nb - 1u) * 16u + 14u] << 32) | src[(nb - 1u) * 16u + 15u];
+        const uint32_t n = uniform((uint32_t)(bits >> 3));
+        if ((bits >> 3) > (uint64_t)NMAX || n <= n_above || n > b.max_input || (uint64_t)n + 9u > (uint64_t)nb * 64u || n == 0) continue;
+
+        // ---- the message into LDS, in byte order (the arena holds its big-endian words as native dwords), zeros behind it
+        const uint32_t words = (n + 3u) >> 2, all_words = (n + zw::kPad + 8u) >> 2;
+        for (uint32_t w = tid; w < all_words; w += 256u) sh.data[w] = w < words ? __builtin_bswap32(src[w]) : 0u;
+        for (uint32_t k = tid; k < kBuckets / 8u; k += 256u) reinterpret_cast<uint4*>(sh.a.bucket)[k] = make_uint4(0, 0, 0, 0);
+        for (uint32_t k = tid; k < uint32_t(zd::kLCodes + 2); k += 256u) sh.lt_fc[k] = k == uint32_t(zd::kEndBlock) ? 1 : 0;   // init_block
+        if (tid < uint32_t(zd::kDCodes + 2)) sh.dt_fc[tid] = 0;
+        if (tid == 0) { sh.sum_a = 0; sh.sum_b = 0; }
+        __syncthreads();
+        if ((n & 3u) && tid == 0) sh.data[n >> 2] &= (1u << ((n & 3u) * 8u)) - 1u;   // the padding's 0x80 and what follows it
+        __syncthreads();
+        const uint32_t* const d = sh.data;
+        {   // adler32: a = 1 + the bytes' sum, b = n + the sum of (n - i) * byte i, both mod 65521; a thread takes 64 bytes
+            uint32_t a = 0, bsum = 0;
+            const uint32_t from = tid * 64u;
+            if (from < n) {
+                const uint32_t upto = from + 64u < n ? from + 64u : n;
+                for (uint32_t w = from >> 2; w * 4u < upto; ++w) {          // (bytes behind n are zero)
+                    const uint32_t v = d[w], at = n - w * 4u;
+                    const uint32_t b0 = v & 0xffu, b1 = (v >> 8) & 0xffu, b2 = (v >> 16) & 0xffu, b3 = v >> 24;
+                    a += b0 + b1 + b2 + b3;
+                    bsum += at * b0 + (at - 1u) * b1 + (at - 2u) * b2 + (at - 3u) * b3;   // (a factor wraps only where its byte is zero)
+                }
+                atomicAdd(&sh.sum_a, a);
+                atomicAdd(&sh.sum_b, (unsigned long long)bsum);
+            }
+        }
+        lap(0);
+
+        // ---- the hash chains, by the serial wave, 64 positions at a time.  A lane's link is the nearest lane below it
+        // with the same bucket, else the bucket's head from before the chunk; the last lane of a bucket becomes its head.
+        // Which lanes share a lane's bucket: one ballot per bit of the bucket number, the same work whatever the content.
+        if (serial) {
+            for (uint32_t base = 0; base + 2u < n; base += 64u) {
+                const uint32_t p = base + lane;
+                const bool valid = p + 2u < n;
+                const uint32_t h = valid ? zw::hash_of(zw::ld32(d, p)) : 0u;
+                const uint32_t key = h & (kBuckets - 1u);
+                const uint32_t old = valid ? sh.a.bucket[key] : 0u;
+                uint64_t same = __ballot(valid);
+#pragma unroll
+                for (int bit = 0; bit < BKBITS; ++bit) {
+                    const bool set = (key >> bit) & 1u;
+                    const uint64_t with = __ballot(set);
+                    same &= set ? with : ~with;
+                }
+                if (valid) {
+                    const uint64_t below = same & ((1ull << lane) - 1ull);
+                    const uint32_t lk = below ? base + 63u - (uint32_t)__builtin_clzll(below) : old;
+                    sh.entry[p] = uint16_t(chain.make(lk, h));
+                    if ((same >> lane) >> 1 == 0) sh.a.bucket[key] = uint16_t(p);
+                }
+                // (the wave's LDS accesses are served in the order it issues them: the next chunk's loads see these stores)
+            }
+        }
+        if (tid == 0) { sh.grab[0] = 0; sh.grab[1] = 0; }
+        __syncthreads();
+        lap(1);
+
+        // ---- the scan, tile by tile: three waves search a tile's positions while the serial wave decides over the tile
+        // before.  A searching lane takes the next position of the tile that nobody has, walks its chain, stores the
+        // answer and takes another: chains are of very different lengths, and a wave steps as slowly as its longest.
+        zw::Scan sc;
+        uint32_t last_lit = 0;
+        const uint32_t tiles = (n + kScanTile - 1u) / kScanTile;
+        for (uint32_t tile = 0; tile <= tiles; ++tile) {
+            // A searching wave: its lanes take positions of tile `t` until none is left.
+            auto search_tile = [&](uint32_t t) {
+                const uint32_t first = t * kScanTile;
+                zw::Found* const found = sh.found[t & 1u];
+                uint32_t* const grab = &sh.grab[t & 1u];
+                zw::Walk k;
+                bool holds = false, dry = false;             // holds: k's answer is not stored yet; dry: the tile has no position left
+                for (;;) {
+                    const uint64_t done = __ballot(k.state == zw::Walk::kDone);
+                    if (done == ~0ull || (!dry && __builtin_popcountll(done) >= int(kRefill))) {
+                        if (k.state == zw::Walk::kDone && holds) { found[k.p - first] = zw::walk_result(k); holds = false; }
+                        if (!dry) {                           // as many positions as there are free lanes, with one atomic
+                            const uint32_t want = (uint32_t)__builtin_popcountll(done), leader = (uint32_t)__builtin_ctzll(done);
+                            uint32_t got = 0;
+                            if (lane == leader) got = atomicAdd(grab, want);
+                            got = lane_value(got, leader);
+                            dry = got + want >= kScanTile;
+                            if (k.state == zw::Walk::kDone) {
+                                const uint32_t at = got + (uint32_t)__builtin_popcountll(done & ((1ull << lane) - 1ull));
+                                const uint32_t p = first + at;
+                                if (at < kScanTile && p + 16u <= n) { zw::walk_begin(k, d, n, chain, p); holds = true; }   // (the last 15 are not asked for)
+                            }
+                        }
+                        if (__ballot(k.state != zw::Walk::kDone || holds) == 0) break;
+                    }
+#pragma unroll
+                    for (uint32_t hop = 0; hop < kHopsInARow; ++hop)
+                        if (k.state == zw::Walk::kHop) zw::walk_hop(k, d, chain);
+                    if (k.state == zw::Walk::kCompare) zw::walk_compare(k, d);
+                }
+            };
+            if (!serial) {
+                if (tile < tiles) search_tile(tile);
+            } else {
+                __builtin_amdgcn_s_setprio(3);               // the one wave everything waits for
+                if (tile + 1u < tiles && lane == 0) sh.grab[(tile + 1u) & 1u] = 0;
+                if (tile > 0) {
+                    const uint32_t first = (tile - 1u) * kScanTile, end = first + kScanTile;
+                    const zw::Found* const found = sh.found[(tile - 1u) & 1u];
+                    uint32_t part = ~0u;
+                    zw::Found fq{0, 0};
+                    uint64_t plains = 0;
+                    // a symbol as the scan notes it: lane 0 stores two values that are the same in all lanes, and waits for nothing
+                    auto note = [&](const zw::Symbol& sy) {
+                        if (lane == 0) { sh.a.sym.d_buf[last_lit] = uint16_t(sy.code); sh.a.sym.l_buf[last_lit] = uint8_t(sy.lc); }
+                        ++last_lit;
+                    };
+                    // The decisions proper.  Everything they work with is the same in all lanes, and said to be (uniform()),
+                    // so that the compiler keeps it in scalar registers and branches instead of masking lanes.
+                    sc.strstart = uniform(sc.strstart); sc.match_length = uniform(sc.match_length); sc.match_start = uniform(sc.match_start);
+                    sc.prev_length = uniform(sc.prev_length); sc.prev_match = uniform(sc.prev_match);
+                    sc.match_available = uniform(sc.match_available ? 1u : 0u) != 0u;
+                    last_lit = uniform(last_lit);
+                    while (sc.strstart + 16u <= n && sc.strstart < end) {
+                        const uint32_t q = (sc.strstart - first) >> 6, idx = (sc.strstart - first) & 63u;
+                        if (q != part) {                      // this lane's answer among the 64 positions, and which of them are plain
+                            part = q;
+                            fq = found[q * 64u + lane];
+                            plains = __ballot(zw::plain(fq) && first + q * 64u + lane + 16u <= n);
+                        }
+                        // a run of plain positions entered with no match pending: literals, by as many lanes
+                        uint32_t run = 0;
+                        if (sc.match_length < uint32_t(zd::kMinMatch)) {
+                            const uint64_t rest = plains >> idx;                    // bit k: position idx + k is plain
+                            run = rest == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~rest);   // (idx > 0 shifts zeros in: never all ones then)
+                        }
+                        if (run > 1u) {
+                            const uint32_t skip = sc.match_available ? 0u : 1u;     // the scan's very first position only opens the window
+                            if (lane >= skip && lane < run) {
+                                sh.a.sym.d_buf[last_lit + lane - skip] = uint16_t(zw::kLiteral + sc.strstart + lane - 1u);
+                                sh.a.sym.l_buf[last_lit + lane - skip] = 0;
+                            }
+                            last_lit += run - skip;
+                            sc.strstart += run;
+                            sc.match_available = true;
+                            sc.prev_length = sc.match_length = zw::kNone;
+                            continue;
+                        }
+                        const zw::Found fi{lane_value(fq.r32, idx), lane_value(fq.r128, idx)};
+                        const zw::Symbol sy = zw::scan_step(sc, d, n, fi);
+                        if (sy.emit) note(sy);
+                    }
+                    while (sc.strstart < n && sc.strstart < end) {       // the last 15 positions: zlib's own search, one by one
+                        const zw::Symbol sy = zw::scan_step_tail(sc, d, n, chain);
+                        if (sy.emit) note(sy);
+                    }
+                    if (sc.strstart >= n && tile == tiles) {
+                        if (sc.match_available) note(zw::Symbol{true, zw::kLiteral + sc.strstart - 1u, 0});
+                        if (lane == 0) sh.n_sym = last_lit;
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                lap(3);
+                if (tile < tiles) search_tile(tile);         // and then it searches with the others
+            }
+            __syncthreads();
+            if (serial) lap(2);                             // (what the serial wave waited for the searches)
+        }
+        // ---- the symbols into zlib's form (a literal's byte is read only now) and their counts, a symbol per thread
+        const uint32_t n_sym = sh.n_sym;
+        for (uint32_t k = tid; k < n_sym; k += 256u) {
+            uint32_t dist, lc, dcode;
+            const uint32_t lcode = zw::settle(d, sh.a.sym.d_buf[k], sh.a.sym.l_buf[k], dist, lc, dcode);
+            sh.a.sym.d_buf[k] = uint16_t(dist); sh.a.sym.l_buf[k] = uint8_t(lc);
+            bump_lds(&sh.lt_fc[lcode]);
+            if (dcode != ~0u) bump_lds(&sh.dt_fc[dcode]);
+        }
+        if (tid == 0) {
+            uint32_t* const meta = g_meta + in_group * kMeta;
+            meta[0] = (uint32_t)i; meta[1] = (uint32_t)(i >> 32); meta[2] = n; meta[3] = n_sym;
+            meta[4] = (uint32_t)((sh.sum_b + n) % 65521u) << 16 | (sh.sum_a + 1u) % 65521u;
+        }
+        __syncthreads();
+
+        // ---- symbols and counts to the object's slot of the workgroup's scratch
+        {
+            uint32_t* const sym = reinterpret_cast<uint32_t*>(scratch + (uint64_t)in_group * Scratch::kSymBytes);
+            const uint32_t* const from = reinterpret_cast<const uint32_t*>(&sh.a.sym);
+            constexpr uint32_t kSymWords = (3u * (NMAX + 2) + 3u) / 4u;          // d_buf and l_buf lie back to back in LDS as in the slot
+            const uint32_t d_words = (2u * n_sym + 3u) / 4u, l_first = (2u * (NMAX + 2)) / 4u, l_words = (n_sym + 3u) / 4u;
+            for (uint32_t k = tid; k < d_words && k < kSymWords; k += 256u) sym[k] = from[k];
+            for (uint32_t k = tid; k < l_words && l_first + k < kSymWords; k += 256u) sym[l_first + k] = from[l_first + k];
+            // the counts into the tree arrays as Deflater::setup lays them out: lt_fc, lt_dl, dt_fc, dt_dl, bt_fc, ...
+            for (uint32_t k = tid; k < uint32_t(zd::kLCodes); k += 256u) g_small[k * kGroup + in_group] = sh.lt_fc[k];
+            if (tid < uint32_t(zd::kDCodes)) g_small[(2u * zd::kLtN + tid) * kGroup + in_group] = sh.dt_fc[tid];
+            if (tid < uint32_t(zd::kBLCodes)) g_small[(2u * zd::kLtN + 2u * zd::kDtN + tid) * kGroup + in_group] = 0;
+        }
+        lap(4);
+        if (++in_group == kGroup) { write_blocks(in_group); in_group = 0; }
+        else __syncthreads();                               // the next object reuses every array
+        ++spent[7];
+    }
+    if (in_group) write_blocks(in_group);
+    if (b.trace && serial && lane == 0)
+        for (int k = 0; k < 8; ++k) if (spent[k]) atomicAdd(reinterpret_cast<unsigned long long*>(&b.trace[k]), (unsigned long long)spent[k]);
+}
+
 uint64_t deflate_workspace_bytes(uint32_t lanes) { return (uint64_t)lanes * (zd::work_bytes() + zd::small_bytes()); }
 uint64_t deflate_tables_bytes() { return sizeof(zd::Tables); }
 void deflate_make_tables(void* host_dst) { zd::make_tables(*static_cast<zd::Tables*>(host_dst)); }
 uint32_t deflate_bound(uint32_t framed_len) { return zd::bound(framed_len); }
 uint32_t deflate_max_input() { return zd::kMaxInput; }
 
-hipError_t launch_deflate(const DeflateBatch& b, uint32_t lanes, hipStream_t stream)
+uint32_t deflate_wave_max_input() { return zw::kMaxInput; }
+
+// Workgroups a launch of one class keeps resident: what the device holds of them at once (LDS decides).
+template <int NMAX, int BKBITS, int POSBITS>
+static hipError_t wave_class_shape(uint32_t* groups, uint64_t* scratch_bytes)
+{
+    static int per_cu = 0, cus = 0;                        // the same on every gfx950; asked once
+    if (!per_cu) {
+        int dev = 0, n = 0, c = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, deflate_wave_kernel<NMAX, BKBITS, POSBITS>, 256, 0);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        per_cu = n > 0 ? n : 1; cus = c > 0 ? c : 256;
+    }
+    *groups = uint32_t(per_cu) * uint32_t(cus);
+    *scratch_bytes = uint64_t(*groups) * WaveScratch<NMAX>::kBytes;
+    return hipSuccess;
+}
+
+template <int NMAX, int BKBITS, int POSBITS>
+static hipError_t launch_wave_class(const DeflateBatch& b, uint32_t n_above, hipStream_t stream)
+{
+    uint32_t groups = 0;
+    uint64_t bytes = 0;
+    hipError_t e = wave_class_shape<NMAX, BKBITS, POSBITS>(&groups, &bytes);
+    if (e != hipSuccess) return e;
+    if (groups > b.n) groups = b.n;
+    hipLaunchKernelGGL((deflate_wave_kernel<NMAX, BKBITS, POSBITS>), dim3(groups), dim3(256), 0, stream, b, n_above);
+    return hipGetLastError();
+}
+
+// Device memory the wave kernels need behind DeflateBatch::workspace: the largest class's scratch (the classes run one
+// after the other).  With the device current.
+hipError_t deflate_wave_workspace_bytes(uint64_t* out)
+{
+    uint32_t g;
+    uint64_t bytes = 0, most = 0;
+    hipError_t e = wave_class_shape<1536, 12, 11>(&g, &bytes); most = bytes > most ? bytes : most;
+    if (e == hipSuccess) { e = wave_class_shape<4608, 13, 13>(&g, &bytes); most = bytes > most ? bytes : most; }
+    if (e == hipSuccess) { e = wave_class_shape<9216, 14, 14>(&g, &bytes); most = bytes > most ? bytes : most; }
+    if (e == hipSuccess) { e = wave_class_shape<16382, 15, 14>(&g, &bytes); most = bytes > most ? bytes : most; }
+    *out = most;
+    return e;
+}
+
+// All objects of up to deflate_wave_max_input() bytes: one launch per size class, each over the whole batch.
+hipError_t launch_deflate_wave(const DeflateBatch& b, hipStream_t stream)
 {
     if (b.n == 0) return hipSuccess;
+    if (!b.tables_raw || !b.workspace) return hipErrorInvalidValue;
+    static_assert(zw::kClasses[0].nmax == 1536 && zw::kClasses[1].bkbits == 13 && zw::kClasses[2].posbits == 14 && zw::kClasses[3].nmax == 16382,
+                  "the launches below are zwave.h's classes");
+    hipError_t e = launch_wave_class<1536, 12, 11>(b, 0, stream);
+    if (e == hipSuccess) e = launch_wave_class<4608, 13, 13>(b, 1536, stream);
+    if (e == hipSuccess) e = launch_wave_class<9216, 14, 14>(b, 4608, stream);
+    if (e == hipSuccess) e = launch_wave_class<16382, 15, 14>(b, 9216, stream);
+    return e;
+}
+
+// The lane kernel, for the objects longer than only_above (at most deflate_max_input()); its tables: lane_workspace.
+hipError_t launch_deflate(DeflateBatch b, uint8_t* lane_workspace, uint32_t lanes, uint32_t only_above, hipStream_t stream)
+{
+    if (b.n == 0) return hipSuccess;
+    b.workspace = lane_workspace;
     if (!b.workspace || !b.tables_raw || lanes < 64) return hipErrorInvalidValue;
     // (Spreading a batch of fewer objects than lanes over more waves with fewer lanes at work each was measured and is
     // slower: 32 768 text-like objects 82 ms on 1 024 half-empty waves against 78 ms on 512 full ones.)
     uint32_t waves = lanes / 64u;
     const uint64_t need = ((uint64_t)b.n + 63u) / 64u;
     if (waves > need) waves = (uint32_t)need;
-    hipLaunchKernelGGL(deflate_kernel, dim3(waves), dim3(64), 0, stream, b);
+    hipLaunchKernelGGL(deflate_kernel, dim3(waves), dim3(64), 0, stream, b, only_above);
     return hipGetLastError();
 }
 

@@ -224,11 +224,15 @@ void vit_hasher_destroy(vit_hasher* h)
         if (q.ev_b) (void)hipEventDestroy(q.ev_b);
         if (q.sort_scratch) (void)hipFree(q.sort_scratch);
         if (q.z_workspace) (void)hipFree(q.z_workspace);
+        if (q.z_scratch) (void)hipFree(q.z_scratch);
         if (q.z_tables) (void)hipFree(q.z_tables);
         if (q.z_done) (void)hipEventDestroy(q.z_done);
-        if (q.z_out) (void)hipFree(q.z_out);
-        if (q.z_meta_d) (void)hipFree(q.z_meta_d);
-        if (q.z_meta_h) (void)hipHostFree(q.z_meta_h);
+        for (Queue::StreamSet& z : q.z) {
+            if (z.d_out) (void)hipFree(z.d_out);
+            if (z.h_out) (void)hipHostFree(z.h_out);
+            if (z.meta_d) (void)hipFree(z.meta_d);
+            if (z.meta_h) (void)hipHostFree(z.meta_h);
+        }
         for (hipEvent_t e : q.timing) (void)hipEventDestroy(e);
         for (hipStream_t st : q.stream) if (st) (void)hipStreamDestroy(st);
     }
@@ -271,6 +275,7 @@ int vit_hasher_set_option(vit_hasher* h, const char* name, uint64_t value)
     else if (k == "debug_fail_deflate") h->opt.fail_deflate = value != 0;
     else if (k == "debug_corrupt_deflate") h->opt.corrupt_deflate = value != 0;
     else if (k == "deflate_max_bytes") h->opt.deflate_max_bytes = std::min<uint64_t>(value, vit::deflate_max_input());
+    else if (k == "deflate_chunk_bytes") h->opt.deflate_chunk_bytes = std::min<uint64_t>(std::max<uint64_t>(value, 1u << 20), 1ull << 30);
     else if (k == "deflate_lanes") h->opt.deflate_lanes = uint32_t(std::min<uint64_t>(std::max<uint64_t>(value, 64), 1u << 20) / 64 * 64);
     else if (k == "sched_waves") h->opt.sched_waves = uint32_t(value > 8 ? 8 : value);
     else if (k == "sched_share_below") h->opt.sched_share_below = uint32_t(value > 0xFFFFFFFEull ? 0xFFFFFFFEu : value);

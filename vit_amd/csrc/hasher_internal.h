@@ -79,12 +79,16 @@ struct Queue {
     bool      grew_this_call = false;                      // a pinned staging arena was (re)allocated during the call
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
     void* sort_scratch = nullptr; size_t sort_scratch_bytes = 0;   // vit_bin_order_device
-    uint8_t* z_workspace = nullptr; uint32_t z_lanes = 0;          // vit_deflate_arena_device: tables of the objects in flight
+    uint8_t* z_workspace = nullptr; uint32_t z_lanes = 0;          // the lane deflate kernel's tables of the objects in flight
+    uint8_t* z_scratch = nullptr;                                  // the wave deflate kernels' scratch
     void* z_tables = nullptr;                                      // ... and zlib's constant tables
     hipEvent_t z_done = nullptr;                                   // ... and the end of the last launch that used them: the next one, on
                                                                    // whatever stream, waits for it (one workspace per queue)
-    uint8_t* z_out = nullptr; uint64_t z_out_cap = 0;              // vit_deflate_objects: a chunk's streams on the device
-    uint8_t* z_meta_d = nullptr; uint8_t* z_meta_h = nullptr; uint64_t z_meta_cap = 0;   // ... their offsets and lengths (12 bytes per object)
+    struct StreamSet {                                             // vit_deflate_objects, per chunk in flight (two alternate):
+        uint8_t* d_out = nullptr; uint64_t d_out_cap = 0;          // the chunk's streams on the device
+        uint8_t* h_out = nullptr; uint64_t h_out_cap = 0;          // ... and in pinned memory, when the caller's buffer is not pinned
+        uint8_t* meta_d = nullptr; uint8_t* meta_h = nullptr; uint64_t meta_cap = 0;   // ... their offsets and lengths (12 bytes per object)
+    } z[2];
     std::vector<hipEvent_t> timing;                       // pool for vit_time_hash_device
     uint64_t* wave_trace = nullptr;                       // diagnostics: device buffer, 32 bytes per wave, that the next
                                                           // launches fill with their waves' timeline (tools/wave_timeline.py)
@@ -131,8 +135,10 @@ struct Options {
     bool fail_deflate = false;                            // option debug_fail_deflate: vit_deflate_objects fails (tests)
     bool corrupt_deflate = false;                         // option debug_corrupt_deflate: one byte of the first stream of every
                                                           // vit_deflate_objects call is flipped (tests of the caller's checks)
-    uint64_t deflate_max_bytes = 16384;                   // vit_deflate_objects: longer objects (framed) are left to the host
-    uint32_t deflate_lanes = 65536;                       // objects the deflate kernel keeps in flight (181 KiB of device memory each)
+    uint64_t deflate_max_bytes = 16382;                   // longer objects (framed) are left to the host; up to this default a wave
+                                                          // deflates an object in LDS, beyond it a lane with tables in device memory
+    uint64_t deflate_chunk_bytes = 64ull << 20;           // vit_deflate_objects: packed bytes per chunk (two chunks are in flight)
+    uint32_t deflate_lanes = 4096;                        // objects the LANE kernel keeps in flight (181 KiB of device memory each)
 };
 
 // Rates the auto policy balances with, bytes per second; 0 = not measured yet.

@@ -125,16 +125,28 @@ struct DeflateBatch {
     const uint64_t* offsets; const uint32_t* nblocks; uint32_t n;
     const uint32_t* order;        // optional: slot s deflates object order[s] (objects sorted by length, so that a wave's 64 end together)
     uint8_t*        out; const uint64_t* out_off; uint32_t* out_len;
-    uint8_t*        workspace;
+    uint8_t*        workspace;    // the wave kernels' scratch (see launch_deflate_wave)
     const void*     tables_raw;   // device copy of what deflate_make_tables() wrote
     uint32_t*       status;
+    uint32_t        max_input;    // objects of more framed bytes are nobody's here (their out_len stays as it is)
+    uint64_t*       trace;        // diagnostics, normally nullptr: 8 counters the wave kernels add their shader-clock cycles to,
+                                  // by phase (load, chains, searches, decisions, trees + head, content, checksum + store, objects)
 };
 uint64_t deflate_workspace_bytes(uint32_t lanes);
 uint64_t deflate_tables_bytes();
 void deflate_make_tables(void* host_dst);
 uint32_t deflate_bound(uint32_t framed_len);
 uint32_t deflate_max_input();
-hipError_t launch_deflate(const DeflateBatch& b, uint32_t lanes, hipStream_t stream);
+// Two kernels share the work.  launch_deflate_wave: one object per workgroup with its tables in LDS, for every object
+// of up to deflate_wave_max_input() framed bytes (one deflate block); DeflateBatch::workspace is then
+// deflate_wave_workspace_bytes() of scratch (symbols and tree arrays of the objects in flight).  launch_deflate: one
+// object per LANE with its tables in lane_workspace (deflate_workspace_bytes(lanes)), for the objects longer than
+// only_above.  Each writes out_len only for the objects it does (and 0 for a slot with bad input); out_len must be
+// zero beforehand for the rest to read as "the host's".
+hipError_t launch_deflate_wave(const DeflateBatch& b, hipStream_t stream);
+uint32_t deflate_wave_max_input();
+hipError_t deflate_wave_workspace_bytes(uint64_t* out);
+hipError_t launch_deflate(DeflateBatch b, uint8_t* lane_workspace, uint32_t lanes, uint32_t only_above, hipStream_t stream);
 
 // Compute-only ceiling: every lane runs `blocks_per_lane` SHA-1 compressions on
 // register-resident data (no loads in the loop).  out: one dword per lane.

@@ -550,9 +550,6 @@ bool ObjectStore::ensureDeflateHasher()
         return false;
     }
     gpu_->set_option(deflate_hasher_, "pack_threads", uint64_t(std::max(2, io_threads_ / 4)));
-    // A batch of the store holds 128 MiB: some 32768 objects of 4 KiB.  That many in flight (5.9 GB of tables on the
-    // device) keeps a launch as short as the library's default of twice as many would.
-    gpu_->set_option(deflate_hasher_, "deflate_lanes", 32768);
     if (const char* e = std::getenv("VIT_DEVICE_DEFLATE_LANES")) gpu_->set_option(deflate_hasher_, "deflate_lanes", std::strtoull(e, nullptr, 10));
     if (const char* e = std::getenv("VIT_DEVICE_DEFLATE_MAX")) gpu_->set_option(deflate_hasher_, "deflate_max_bytes", std::strtoull(e, nullptr, 10));
     if (std::getenv("VIT_DEBUG_FAIL_DEFLATE")) gpu_->set_option(deflate_hasher_, "debug_fail_deflate", 1);       // tests
@@ -818,7 +815,7 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
     // launch lasts as long as its longest object on one lane, about 10 us per byte), fewer are done sooner by the
     // host threads.
     const bool may_device = tree_side_ == Side::GPU && device_deflate_ && store_ && (deflate_level_ == -1 || deflate_level_ == 6);
-    uint64_t device_min_objects = 16384, device_max_bytes = 16384;
+    uint64_t device_min_objects = 16384, device_max_bytes = 16382;     // up to there a wave deflates an object in LDS, no device tables
     if (const char* e = std::getenv("VIT_DEVICE_DEFLATE_MIN")) device_min_objects = std::strtoull(e, nullptr, 10);
     if (const char* e = std::getenv("VIT_DEVICE_DEFLATE_MAX")) device_max_bytes = std::strtoull(e, nullptr, 10);
     const size_t ns = may_device ? 4 : 3;

@@ -96,7 +96,7 @@ public:
     // reference's readObject and git read them); level 1 deflates about three times faster, level 0 stores.
     void setDeflateLevel(int level) { deflate_level_ = level < -1 ? -1 : (level > 9 ? 9 : level); }
     // Where the small objects of a write-tree are deflated.  true (default): batches that hold at least 16384 objects
-    // of up to 16 KiB are deflated on the GPU, by the kernel that writes the zlib library's own bytes
+    // of up to 16 KiB (one deflate block) are deflated on the GPU, by the kernel that writes the zlib library's own bytes
     // (vit_deflate_objects; their longer objects, and smaller batches, still go to host threads), so that the host
     // threads are left with creating files.  Only at the default level: any other level is the host's.
     void setDeviceDeflate(bool on) { device_deflate_ = on; }

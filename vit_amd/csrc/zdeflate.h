@@ -489,35 +489,50 @@ template <class In> struct Deflater {
         else send_bits(s.lt_fc[kEndBlock], s.lt_dl[kEndBlock]);
     }
 
-    // _tr_flush_block: the block is input bytes [block_start, block_start + stored_len)
-    ZD_FN void flush_block(uint32_t block_start, uint32_t stored_len, int last)
+    // _tr_flush_block in two halves (a caller may want to write a stored block's bytes, or a block's symbols, itself):
+    // plan_block builds the three trees from the counts and chooses the block's form, emit_block writes it.
+    enum { kStored = 0, kFixed = 1, kDynamic = 2 };
+    int max_blindex_;
+    ZD_FN int plan_block(uint32_t stored_len)
     {
         s.l_max_code = build_tree(s.lt_fc, s.lt_dl, kLCodes, 0);
         s.d_max_code = build_tree(s.dt_fc, s.dt_dl, kDCodes, 1);
-        const int max_blindex = build_bl_tree();
+        max_blindex_ = build_bl_tree();
         uint32_t opt_lenb = (s.opt_len + 3 + 7) >> 3;
         const uint32_t static_lenb = (s.static_len + 3 + 7) >> 3;
         if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
-        if (stored_len + 4 <= opt_lenb) {
+        if (stored_len + 4 <= opt_lenb) return kStored;
+        return static_lenb == opt_lenb ? kFixed : kDynamic;
+    }
+    // What precedes a block's content: the three header bits; for a stored block the padding to a byte and the two
+    // length words; for a dynamic block the description of its trees.
+    ZD_FN void emit_block_head(int kind, uint32_t stored_len, int last)
+    {
+        if (kind == kStored) {
             send_bits(uint32_t((0 << 1) + last), 3);
             bi_windup();
             put_short(stored_len & 0xffff);
             put_short(~stored_len & 0xffff);
-            for (uint32_t i = 0; i < stored_len; ++i) put_byte(at(block_start + i));
-        } else if (static_lenb == opt_lenb) {
+        } else if (kind == kFixed) {
             send_bits(uint32_t((1 << 1) + last), 3);
-            compress_block(true);
         } else {
             send_bits(uint32_t((2 << 1) + last), 3);
-            const int lcodes = s.l_max_code + 1, dcodes = s.d_max_code + 1, blcodes = max_blindex + 1;
+            const int lcodes = s.l_max_code + 1, dcodes = s.d_max_code + 1, blcodes = max_blindex_ + 1;
             send_bits(uint32_t(lcodes - 257), 5);
             send_bits(uint32_t(dcodes - 1), 5);
             send_bits(uint32_t(blcodes - 4), 4);
             for (int rank = 0; rank < blcodes; rank++) send_bits(s.bt_dl[s.t->bl_order[rank]], 3);
             send_tree(s.lt_dl, lcodes - 1);
             send_tree(s.dt_dl, dcodes - 1);
-            compress_block(false);
         }
+    }
+    // _tr_flush_block: the block is input bytes [block_start, block_start + stored_len)
+    ZD_FN void flush_block(uint32_t block_start, uint32_t stored_len, int last)
+    {
+        const int kind = plan_block(stored_len);
+        emit_block_head(kind, stored_len, last);
+        if (kind == kStored) { for (uint32_t i = 0; i < stored_len; ++i) put_byte(at(block_start + i)); }
+        else compress_block(kind == kFixed);
         init_block();
         if (last) bi_windup();
     }
@@ -527,22 +542,33 @@ template <class In> struct Deflater {
     // the tables it must index live in memory.  The State is brought up to date around the
     // block flushes, which happen once in 16383 symbols.
     // The whole stream for input [0, n).  Returns its length, 0 if out_cap was too small.
-    ZD_FN uint32_t run(const Tables* tables, const Work& work, uint32_t n)
+    // Where everything is: the small arrays carved out of the workspace.  Touches no memory.
+    ZD_FN void setup(const Tables* tables, const Work& work, uint32_t n)
     {
         s.t = tables; s.w = work; s.n = n;
         s.pending = 0; s.bi_buf = 0; s.bi_valid = 0; s.overflow = false;
-        {
-            uint16_t* p = work.small;
-            const uint32_t st = work.small_stride;
-            auto take = [&](int entries) { Arr16 a{p, st}; p += uint32_t(entries) * st; return a; };
-            s.lt_fc = take(kLtN); s.lt_dl = take(kLtN);
-            s.dt_fc = take(kDtN); s.dt_dl = take(kDtN);
-            s.bt_fc = take(kBtN); s.bt_dl = take(kBtN);
-            s.bl_count = take(16); s.next_code = take(16);
-            s.heap = Arr32{work.heap, st};
-        }
+        uint16_t* p = work.small;
+        const uint32_t st = work.small_stride;
+        auto take = [&](int entries) { Arr16 a{p, st}; p += uint32_t(entries) * st; return a; };
+        s.lt_fc = take(kLtN); s.lt_dl = take(kLtN);
+        s.dt_fc = take(kDtN); s.dt_dl = take(kDtN);
+        s.bt_fc = take(kBtN); s.bt_dl = take(kBtN);
+        s.bl_count = take(16); s.next_code = take(16);
+        s.heap = Arr32{work.heap, st};
+        s.opt_len = s.static_len = 0;
+        s.last_lit = 0;
+    }
+    // The state before the first input byte: an empty block, the two bytes every stream starts with.
+    ZD_FN void begin(const Tables* tables, const Work& work, uint32_t n)
+    {
+        setup(tables, work, n);
         init_block();
         put_byte(0x78); put_byte(0x9c);                                   // deflate, 32 KiB window, default level
+    }
+
+    ZD_FN uint32_t run(const Tables* tables, const Work& work, uint32_t n)
+    {
+        begin(tables, work, n);
 
         const In input = in;
         const Arr16 head = work.head, prev = work.prev, d_buf = work.d_buf;
@@ -744,7 +770,15 @@ template <class In> struct Deflater {
         if (last) break;
         }
 
-        // adler32 of the input, big-endian; the input four bytes to a load
+        return finish_stream();
+    }
+
+    // Behind the last block: adler32 of the input, big-endian (the input four bytes to a load).  Returns the stream's
+    // length, 0 if out_cap was too small.
+    ZD_FN uint32_t finish_stream()
+    {
+        const In input = in;
+        const uint32_t n = s.n;
         uint32_t a = 1, b = 0;
         for (uint32_t i = 0; i < n;) {
             const uint32_t end = i + 5552 < n ? i + 5552 : n;           // 5552 is a multiple of four: i stays one
