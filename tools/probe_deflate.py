@@ -11,6 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 check = int(sys.argv[3]) if len(sys.argv) > 3 else min(n, 5000)
 h = vit_amd.Hasher((0,))
+h.set_option("deflate_max_bytes", 65536)       # mixed sizes: the objects beyond what a workgroup takes in LDS too (the lane kernel)
 if os.environ.get("VIT_DEFLATE_LANES"):
     h.set_option("deflate_lanes", int(os.environ["VIT_DEFLATE_LANES"]))
 rng = np.random.default_rng(8)

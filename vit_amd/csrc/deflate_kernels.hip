@@ -69,11 +69,6 @@ __global__ __launch_bounds__(64) void deflate_kernel(DeflateBatch b, uint32_t on
     zd::Deflater<ArenaBytes> d;
 
     for (uint64_t first = (uint64_t)blockIdx.x * 64u; first < b.n; first += (uint64_t)gridDim.x * 64u) {
-        // zlib starts from an empty hash table: the wave clears its 64 interleaved tables together
-        uint4* const hd = reinterpret_cast<uint4*>(head16);
-        for (uint32_t k = lane; k < 64u * zd::kHashSize * 2u / 16u; k += 64u) hd[k] = make_uint4(0, 0, 0, 0);
-        __syncthreads();                                  // one wave: orders the lanes' stores before each other's loads
-
         uint64_t i = first + lane;
         bool mine = i < b.n;
         if (mine && b.order) { i = b.order[i]; if (i >= b.n) { atomicOr(b.status, STATUS_BAD_ORDER); mine = false; } }
@@ -87,6 +82,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(DeflateBatch b, uint32_t on
             if (off > b.arena_bytes || (uint64_t)nb * 64u > b.arena_bytes - off) bad |= STATUS_OUT_OF_BOUNDS;
             if (bad) { atomicOr(b.status, bad); b.out_len[i] = 0; mine = false; }
             else if (nb == 0) { b.out_len[i] = 0; mine = false; }
+            else if ((uint64_t)nb * 64u <= only_above) mine = false;      // a wave kernel's, whatever its padding says (framed + 9 <= 64 nb)
         }
         if (mine) {
             // the framed length is in the padding: the last two dwords of the last block hold it in bits
@@ -95,6 +91,12 @@ __global__ __launch_bounds__(64) void deflate_kernel(DeflateBatch b, uint32_t on
             if (n > (uint64_t)zd::kMaxInput || n + 9u > (uint64_t)nb * 64u) { b.out_len[i] = 0; mine = false; }   // the host's share
             else if (n <= only_above || n > b.max_input) mine = false;      // a wave kernel's object, or the host's
         }
+        if (__ballot(mine) == 0) continue;                // none of the 64 is this kernel's: the tables stay as they are (cleared or unused)
+        // zlib starts from an empty hash table: the wave clears its 64 interleaved tables together
+        uint4* const hd = reinterpret_cast<uint4*>(head16);
+        for (uint32_t k = lane; k < 64u * zd::kHashSize * 2u / 16u; k += 64u) hd[k] = make_uint4(0, 0, 0, 0);
+        __syncthreads();                                  // one wave: orders the lanes' stores before each other's loads
+
         if (mine) {
             w.out = b.out + b.out_off[i];
             w.out_cap = zd::bound((uint32_t)n);
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256, 4) void deflate_wave_kernel(DeflateBatch b, ui
             if (tid == 0 && NMAX == 1536) { if (bad) atomicOr(b.status, bad); b.out_len[i] = 0; }
             continue;
         }
-        if ((uint64_t)nb * 64u > (uint64_t)NMAX + 9u + 63u) continue;         // too long for this class, whatever its padding says
+        if ((uint64_t)nb * 64u > (uint64_t)NMAX + 9u + 63u || (uint64_t)nb * 64u <= n_above) continue;   // too long or too short for this class, whatever its padding says
         const uint32_t* const src = reinterpret_cast<const uint32_t*>(b.arena + off);
         // the framed length is in the padding: the last two dwords of the last block hold it in bits
         const uint64_t bits = ((uint64_t)src[(nb - 1u) * 16u + 14u] << 32) | src[(nb - 1u) * 16u + 15u];
