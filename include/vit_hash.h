@@ -135,7 +135,8 @@ int vit_hasher_device_count(const vit_hasher *h);
  *                         lies in that node's memory); nothing is pinned where a GPU's node is
  *                         unknown or a node has fewer usable CPUs than workers it would get.
  *                         0: workers run where the scheduler puts them
- *  "deflate_max_bytes" "deflate_lanes"   see vit_deflate_objects, vit_deflate_arena_device
+ *  "deflate_max_bytes" "deflate_lanes" "deflate_chunk_bytes"   see vit_deflate_objects,
+ *                         vit_deflate_arena_device
  * Options for tests and diagnostics ("debug_*", "trace", "wave_trace_ptr") are
  * listed in vit_hash_bench.h. */
 int vit_hasher_set_option(vit_hasher *h, const char *name, uint64_t value);
@@ -263,27 +264,38 @@ int vit_bin_order_device(vit_hasher *h, int dev, const uint32_t *d_nblocks, uint
  * (NULL = the queue's own).  d_order (optional, as for vit_hash_arena_device:
  * object indices by length, vit_bin_order) evens out the launches' tails.
  * Two kernels share the work.  An object of up to 16382 framed bytes (one deflate
- * block; the default "deflate_max_bytes") is deflated by one WAVE whose 64 lanes
- * build its hash chains, search them and code its symbols together, with every
- * table in LDS: device memory sees the object once and its stream once, and no
- * workspace exists.  With "deflate_max_bytes" raised (at most 65536, the range in
- * which zlib's window never slides) the longer objects are deflated one per LANE
- * with 181 KiB of tables each in device memory, which the library then allocates
- * for "deflate_lanes" objects in flight (default 4096: 0.74 GB) and keeps with
- * the queue.  Launches on one queue that may use those tables are made to wait
- * for one another, whatever streams they are on. */
+ * block; the default "deflate_max_bytes") is deflated by one WORKGROUP with the
+ * object, its hash chains and the block's symbols in LDS: one wave builds the
+ * chains and runs zlib's decisions, the others walk the chains of the positions
+ * ahead of it; the blocks of 32 objects at a time are then written one per lane
+ * (Huffman trees, codes, bits).  Device memory sees the object once, its symbols
+ * and tree arrays in a scratch of the workgroups in flight (0.64 GB per queue,
+ * allocated on first use and kept), and its stream once.  With
+ * "deflate_max_bytes" raised (at most 65536, the range in which zlib's window
+ * never slides) the longer objects are deflated one per LANE with 181 KiB of
+ * tables each in device memory, which the library then allocates for
+ * "deflate_lanes" objects in flight (default 4096: 0.74 GB) and keeps with the
+ * queue.  Launches on one queue share the scratch and the tables and are made to
+ * wait for one another, whatever streams they are on. */
 int vit_deflate_arena_device(vit_hasher *h, int dev, const void *d_arena, uint64_t arena_bytes,
                              const uint64_t *d_offsets, const uint32_t *d_nblocks,
                              const uint32_t *d_order, uint64_t n,
                              uint8_t *d_out, const uint64_t *d_out_offsets, uint32_t *d_out_lens,
                              void *stream);
 
-/* The same for objects in host memory (pack, copy, kernel, copy back, chunk by
- * chunk, on the hasher's first device queue).  Objects whose framed length exceeds
- * option "deflate_max_bytes" (default 16382, at most 65536) are not done here.
- * out: host memory of at least vit_deflate_out_bytes() bytes, best pinned
- * (vit_arena_alloc).  On return stream i is out[out_off[i] .. out_off[i] +
- * out_len[i]); out_len[i] = 0 means the object is the caller's to deflate. */
+/* The same for objects in host memory, on the hasher's first device queue: chunks
+ * of "deflate_chunk_bytes" packed bytes (default 64 MiB) alternate between two
+ * sets of buffers and two streams, so that the host packs one chunk and brings
+ * home the streams of another while the device deflates a third.  Objects whose
+ * framed length exceeds option "deflate_max_bytes" (default 16382, at most 65536)
+ * are not done here.
+ * out: host memory of at least vit_deflate_out_bytes() bytes.  Pinned memory
+ * (vit_arena_alloc) receives the streams straight from the device; into any
+ * other memory they go through a pinned buffer of the library's, from which the
+ * hasher's threads copy each stream's own bytes (pages of `out` behind a
+ * stream's end are never touched).  On return stream i is out[out_off[i] ..
+ * out_off[i] + out_len[i]); out_len[i] = 0 means the object is the caller's to
+ * deflate. */
 int vit_deflate_objects(vit_hasher *h, const char *type, const uint8_t *const *data,
                         const uint64_t *len, uint64_t n, uint8_t *out, uint64_t out_cap,
                         uint64_t *out_off, uint32_t *out_len);

@@ -2,19 +2,21 @@
 //
 // The reference stores every object as compress(header + content) (src/commit.cpp:98-105), and
 // that call is three quarters of its write-tree.  The arena the hasher stages in device memory
-// holds exactly header + content; this kernel writes the zlib stream for every object of it, one
-// object per lane, with zlib's own choices (zdeflate.h), so the host is left with creating files.
+// holds exactly header + content; the kernels here write the zlib stream for every object of it,
+// with zlib's own choices (zdeflate.h, zwave.h), so the host is left with creating files.
 //
-// One lane runs one object from start to finish: deflate is a serial scan with a hash table, as
-// SHA-1 is a serial chain.  The tables a lane needs (zlib's head and prev arrays, the symbol
-// buffers of a block, the Huffman construction's arrays: 181 KiB) live in device memory, one
-// workspace per wave with the 64 lanes' entries interleaved.  A wave takes 64 objects at a time
-// and moves on to its next 64 when the longest of them is done.  The work is bound by scattered
-// two-byte accesses to those tables (the scan, and the Huffman heap of every block), i.e. by the
-// memory system's transaction rate, not by arithmetic: every lane's object, tables and position are
-// its own, so a wave's memory instruction touches up to 64 cache lines.  Incompressible content runs
-// at 8-11 us per input byte and lane (1.4-2 M objects of 4 KiB per second over the chip), text-like
-// content, whose positions have hash chains to walk, at about four times that.
+// Two kernels.  Objects of up to 16382 framed bytes (one deflate block), which is nearly all of a
+// source tree, are deflated by one workgroup each with every table in LDS (second half of the
+// file).  The longer ones, up to 65536 bytes, by one LANE each (first half): deflate is a serial
+// scan with a hash table, as SHA-1 is a serial chain.  The tables a lane needs (zlib's head and
+// prev arrays, the symbol buffers of a block, the Huffman construction's arrays: 181 KiB) live in
+// device memory, one workspace per wave with the 64 lanes' entries interleaved.  A wave takes 64
+// objects at a time and moves on to its next 64 when the longest of them is done.  That kernel is
+// bound by scattered two-byte accesses to those tables (the scan, and the Huffman heap of every
+// block), i.e. by the memory system's transaction rate, not by arithmetic: every lane's object,
+// tables and position are its own, so a wave's memory instruction touches up to 64 cache lines.
+// Incompressible content runs at 8-11 us per input byte and lane, text-like content, whose
+// positions have hash chains to walk, at about four times that.
 #include "kernels.h"
 #include "zdeflate.h"
 #include "zwave.h"
@@ -113,21 +115,35 @@ __global__ __launch_bounds__(64) void deflate_kernel(DeflateBatch b, uint32_t on
 // The lane kernel above keeps 181 KiB of tables per object in device memory and is bound by their scattered traffic
 // (277 bytes over the fabric per input byte, waves issuing in 7 % of their cycles).  For objects of up to 16382 bytes
 // (one deflate block) the tables shrink to a few times the object (bucket table, chain entries, the block's symbols)
-// and fit a workgroup's share of LDS.  Per object: the message is loaded into LDS; one wave builds the hash chains 64
-// positions at a time; then, 256 positions at a time, every thread searches one position's chain and one wave runs
-// zlib's decisions over the answers; the block's symbols and their counts go to a slot of the workgroup's scratch in
-// device memory.  After kGroup objects the first kGroup threads write one object's block each (trees, codes, bits,
-// checksum: zdeflate.h's own code, the stream straight to its place): a Huffman tree is a serial chain of dependent
-// accesses that lanes cannot share but can each have one of.  Device memory sees the object once, its symbols out
-// and in, and its stream once.  Four size classes (LDS per workgroup, workgroups per CU): up to 1536 bytes (16 KiB, 8),
-// 4608 (33 KiB, 4), 9216 (63 KiB, 2), 16382 (117 KiB, 1); every class is one launch over the batch, each workgroup
-// taking the objects of its class.
+// and fit a workgroup's share of LDS.  Per object: the message is loaded into LDS (and its checksum summed, 64 bytes
+// a thread); one wave, the "serial" one, builds the hash chains 64 positions at a time; then, 512 positions at a
+// time, the lanes of the other three waves walk the chains (a lane takes the next position nobody has, stores the
+// answer, takes another) while the serial wave runs zlib's decisions over the 512 positions before, in scalar
+// registers, and joins the walkers when it is through; the block's symbols are settled (a literal's byte read, the
+// codes counted) by all threads and go, with the counts, to a slot of the workgroup's scratch in device memory.
+// After kGroup objects the first kGroup lanes of the serial wave write one object's block each (trees, codes, bits:
+// zdeflate.h's own code, the stream straight to its place): a Huffman tree is a serial chain of dependent accesses
+// that lanes cannot share but can each have one of.  A block that zlib stores is copied by all threads.  Device
+// memory sees the object once, its symbols out and in, the tree arrays, and its stream once: 10 (text-like) to 20
+// (incompressible) bytes over the fabric per input byte.  Four size classes (LDS per workgroup, workgroups per CU):
+// up to 1536 bytes (22 KiB, 4), 4608 (39 KiB, 4), 9216 (68 KiB, 2), 16382 (121 KiB, 1); every class is one launch
+// over the batch, each workgroup taking the objects of its class.
+// What bounds it (text-like 4 KiB objects, 1.5 M/s): a tile is done when its longest chain is, entry by entry at
+// some 900 clocks an entry in a wave that shares its SIMD with three others; the VALUs are busy 40 % of the time.
 constexpr uint32_t kGroup = 32;                              // objects a workgroup scans before it writes their blocks
-constexpr uint32_t kScanTile = 512;                         // positions searched while the 512 before are decided over
 constexpr uint32_t kRefill = 16;                            // searching lanes that must be free before the wave stops to hand out positions
 constexpr uint32_t kHopsInARow = 2;                         // chain entries a lane looks at between two comparisons
 
+// A class's workgroup: threads, and positions per tile.  The two small classes fit a CU four times with four waves each;
+// of the large ones a CU holds two or one, which then have eight and sixteen waves and longer tiles to keep them busy.
+template <int NMAX> struct WaveClass {
+    static constexpr int kThreads = NMAX <= 4608 ? 256 : NMAX <= 9216 ? 512 : 1024;
+    static constexpr uint32_t kTile = NMAX <= 4608 ? 512 : NMAX <= 9216 ? 1024 : 2048;
+    static constexpr int kWavesPerSimd = 4;                 // 128 registers a thread in every class
+};
+
 template <int NMAX, int BKBITS> struct WaveShared {
+    static constexpr uint32_t kScanTile = WaveClass<NMAX>::kTile;
     uint32_t data[(NMAX + zw::kPad + 8) / 4];               // the framed message, byte i at byte i, zeros behind it
     union {
         uint16_t bucket[1 << BKBITS];                       // while the chains are built
@@ -198,8 +214,9 @@ __device__ __attribute__((noinline)) void write_block_by_lane(const DeflateBatch
 }
 
 template <int NMAX, int BKBITS, int POSBITS>
-__global__ __launch_bounds__(256, 4) void deflate_wave_kernel(DeflateBatch b, uint32_t n_above)
+__global__ __launch_bounds__(WaveClass<NMAX>::kThreads, WaveClass<NMAX>::kWavesPerSimd) void deflate_wave_kernel(DeflateBatch b, uint32_t n_above)
 {
+    constexpr uint32_t kThreads = WaveClass<NMAX>::kThreads, kScanTile = WaveClass<NMAX>::kTile;
     __shared__ WaveShared<NMAX, BKBITS> sh;
     using Scratch = WaveScratch<NMAX>;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -222,10 +239,10 @@ __global__ __launch_bounds__(256, 4) void deflate_wave_kernel(DeflateBatch b, ui
     __syncthreads();
     {
         const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID: wave slot [3:0], SIMD [5:4]
-        if (lane == 0) atomicMin(&sh.elect, ((((hw >> 4) - hw) & 3u) << 2) | wave);
+        if (lane == 0) atomicMin(&sh.elect, ((((hw >> 4) - hw) & 3u) << 4) | wave);
     }
     __syncthreads();
-    const uint32_t serial_wave = sh.elect & 3u;
+    const uint32_t serial_wave = sh.elect & 15u;
     const bool serial = wave == serial_wave;
 
     // One lane per object of the group: the trees, the block's head and its codes, zdeflate.h's code as it is.  A block
@@ -245,7 +262,7 @@ __global__ __launch_bounds__(256, 4) void deflate_wave_kernel(DeflateBatch b, ui
             const uint32_t n = meta[2];
             const uint8_t* const from = b.arena + b.offsets[i];
             uint8_t* const to = b.out + b.out_off[i] + stored_at;
-            for (uint32_t j = tid; j < n; j += 256u) to[j] = from[j ^ 3u];
+            for (uint32_t j = tid; j < n; j += kThreads) to[j] = from[j ^ 3u];
         }
         __syncthreads();
         lap(6);
@@ -274,9 +291,9 @@ __global__ __launch_bounds__(256, 4) void deflate_wave_kernel(DeflateBatch b, ui
 
         // ---- the message into LDS, in byte order (the arena holds its big-endian words as native dwords), zeros behind it
         const uint32_t words = (n + 3u) >> 2, all_words = (n + zw::kPad + 8u) >> 2;
-        for (uint32_t w = tid; w < all_words; w += 256u) sh.data[w] = w < words ? __builtin_bswap32(src[w]) : 0u;
-        for (uint32_t k = tid; k < kBuckets / 8u; k += 256u) reinterpret_cast<uint4*>(sh.a.bucket)[k] = make_uint4(0, 0, 0, 0);
-        for (uint32_t k = tid; k < uint32_t(zd::kLCodes + 2); k += 256u) sh.lt_fc[k] = k == uint32_t(zd::kEndBlock) ? 1 : 0;   // init_block
+        for (uint32_t w = tid; w < all_words; w += kThreads) sh.data[w] = w < words ? __builtin_bswap32(src[w]) : 0u;
+        for (uint32_t k = tid; k < kBuckets / 8u; k += kThreads) reinterpret_cast<uint4*>(sh.a.bucket)[k] = make_uint4(0, 0, 0, 0);
+        for (uint32_t k = tid; k < uint32_t(zd::kLCodes + 2); k += kThreads) sh.lt_fc[k] = k == uint32_t(zd::kEndBlock) ? 1 : 0;   // init_block
         if (tid < uint32_t(zd::kDCodes + 2)) sh.dt_fc[tid] = 0;
         if (tid == 0) { sh.sum_a = 0; sh.sum_b = 0; }
         __syncthreads();
@@ -437,7 +454,7 @@ __global__ __launch_bounds__(256, 4) void deflate_wave_kernel(DeflateBatch b, ui
         }
         // ---- the symbols into zlib's form (a literal's byte is read only now) and their counts, a symbol per thread
         const uint32_t n_sym = sh.n_sym;
-        for (uint32_t k = tid; k < n_sym; k += 256u) {
+        for (uint32_t k = tid; k < n_sym; k += kThreads) {
             uint32_t dist, lc, dcode;
             const uint32_t lcode = zw::settle(d, sh.a.sym.d_buf[k], sh.a.sym.l_buf[k], dist, lc, dcode);
             sh.a.sym.d_buf[k] = uint16_t(dist); sh.a.sym.l_buf[k] = uint8_t(lc);
@@ -457,10 +474,10 @@ __global__ __launch_bounds__(256, 4) void deflate_wave_kernel(DeflateBatch b, ui
             const uint32_t* const from = reinterpret_cast<const uint32_t*>(&sh.a.sym);
             constexpr uint32_t kSymWords = (3u * (NMAX + 2) + 3u) / 4u;          // d_buf and l_buf lie back to back in LDS as in the slot
             const uint32_t d_words = (2u * n_sym + 3u) / 4u, l_first = (2u * (NMAX + 2)) / 4u, l_words = (n_sym + 3u) / 4u;
-            for (uint32_t k = tid; k < d_words && k < kSymWords; k += 256u) sym[k] = from[k];
-            for (uint32_t k = tid; k < l_words && l_first + k < kSymWords; k += 256u) sym[l_first + k] = from[l_first + k];
+            for (uint32_t k = tid; k < d_words && k < kSymWords; k += kThreads) sym[k] = from[k];
+            for (uint32_t k = tid; k < l_words && l_first + k < kSymWords; k += kThreads) sym[l_first + k] = from[l_first + k];
             // the counts into the tree arrays as Deflater::setup lays them out: lt_fc, lt_dl, dt_fc, dt_dl, bt_fc, ...
-            for (uint32_t k = tid; k < uint32_t(zd::kLCodes); k += 256u) g_small[k * kGroup + in_group] = sh.lt_fc[k];
+            for (uint32_t k = tid; k < uint32_t(zd::kLCodes); k += kThreads) g_small[k * kGroup + in_group] = sh.lt_fc[k];
             if (tid < uint32_t(zd::kDCodes)) g_small[(2u * zd::kLtN + tid) * kGroup + in_group] = sh.dt_fc[tid];
             if (tid < uint32_t(zd::kBLCodes)) g_small[(2u * zd::kLtN + 2u * zd::kDtN + tid) * kGroup + in_group] = 0;
         }
@@ -490,7 +507,7 @@ static hipError_t wave_class_shape(uint32_t* groups, uint64_t* scratch_bytes)
     if (!per_cu) {
         int dev = 0, n = 0, c = 0;
         hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, deflate_wave_kernel<NMAX, BKBITS, POSBITS>, 256, 0);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, deflate_wave_kernel<NMAX, BKBITS, POSBITS>, WaveClass<NMAX>::kThreads, 0);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return e;
         per_cu = n > 0 ? n : 1; cus = c > 0 ? c : 256;
@@ -508,7 +525,7 @@ static hipError_t launch_wave_class(const DeflateBatch& b, uint32_t n_above, hip
     hipError_t e = wave_class_shape<NMAX, BKBITS, POSBITS>(&groups, &bytes);
     if (e != hipSuccess) return e;
     if (groups > b.n) groups = b.n;
-    hipLaunchKernelGGL((deflate_wave_kernel<NMAX, BKBITS, POSBITS>), dim3(groups), dim3(256), 0, stream, b, n_above);
+    hipLaunchKernelGGL((deflate_wave_kernel<NMAX, BKBITS, POSBITS>), dim3(groups), dim3(WaveClass<NMAX>::kThreads), 0, stream, b, n_above);
     return hipGetLastError();
 }
 

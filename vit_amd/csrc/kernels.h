@@ -129,8 +129,9 @@ struct DeflateBatch {
     const void*     tables_raw;   // device copy of what deflate_make_tables() wrote
     uint32_t*       status;
     uint32_t        max_input;    // objects of more framed bytes are nobody's here (their out_len stays as it is)
-    uint64_t*       trace;        // diagnostics, normally nullptr: 8 counters the wave kernels add their shader-clock cycles to,
-                                  // by phase (load, chains, searches, decisions, trees + head, content, checksum + store, objects)
+    uint64_t*       trace;        // diagnostics, normally nullptr: 8 counters the workgroup-per-object kernels add their serial wave's
+                                  // shader-clock cycles to, by phase (load + checksum, chains, waiting for the searches, decisions,
+                                  // symbols to scratch, the group's blocks by lanes, stored bytes; last: objects)
 };
 uint64_t deflate_workspace_bytes(uint32_t lanes);
 uint64_t deflate_tables_bytes();

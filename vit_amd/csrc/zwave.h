@@ -1,5 +1,5 @@
-// zwave.h — the same zlib stream as zdeflate.h writes, worked out by the 64 lanes of a GPU wave together on ONE
-// object whose tables fit the wave's share of LDS, instead of by one lane per object with its tables in device memory.
+// zwave.h — the same zlib stream as zdeflate.h writes, worked out by the waves of a GPU workgroup together on ONE
+// object whose tables fit the workgroup's share of LDS, instead of by one lane per object with its tables in device memory.
 //
 // What zlib's default-level deflate (deflate.c: deflate_slow, longest_match) does per input position is a serial
 // chain only in its DECISIONS (take the match found at the position before, or wait for this one's).  Everything
@@ -9,8 +9,8 @@
 //   * the longest match at a position, given how many candidates may be looked at (128, or 32 once the position before
 //     has a match of 8 or more): the first candidate that reaches the greatest length among them.  The length the
 //     position before found (zlib's prev_length) only decides whether that match COUNTS (it must be longer).
-// So a workgroup builds the chains 64 positions at a time, then searches 256 positions at a time, every lane walking
-// its own position's chain and keeping two answers (best of the first 32 candidates, best of the first 128), and only
+// So a workgroup builds the chains 64 positions at a time, then searches a tile of positions at a time, a lane walking
+// one position's chain and keeping two answers (best of the first 32 candidates, best of the first 128), and only
 // then is zlib's decision loop run over those answers, position by position, without touching a chain.  What the
 // scan leaves (the block's symbols and their counts) goes to device memory; the block itself (trees, codes, bits:
 // zdeflate.h's flush_block, trees.c restated) is written one object per LANE for a group of objects at a time, because
@@ -27,8 +27,8 @@
 // match shorter than 16), so the two precomputed answers are what zlib finds.  In the last 15 positions a candidate can
 // reach nice_match without improving; there the decision loop searches in line, with zlib's own loop.
 //
-// This header holds what host and device share: the per-position functions, the decision step, the symbol coder,
-// and an emulation of the whole algorithm in plain C++ (deflate_emulated) that tests/zdeflate_driver.cpp runs against
+// This header holds what host and device share: the per-position functions (a chain walk in steps), the decision step,
+// how a symbol is settled, and an emulation of the whole algorithm in plain C++ (deflate_emulated) that tests/zdeflate_driver.cpp runs against
 // the zlib library on thousands of inputs.  deflate_kernels.hip is the same flow with wave intrinsics for what the
 // emulation does with loops over lanes.
 #pragma once
