@@ -22,11 +22,12 @@
  *                         there when it started and ended (100 MHz clock), its hardware id
  *                         (SIMD, CU, SE, XCD) and its longest object in blocks; 0 = off.
  *                         The deflate kernels that run one workgroup per object take the
- *                         same address for something else: eight 64-bit counters to which
+ *                         same address for something else: fourteen 64-bit counters (128 bytes), to the first eight of which
  *                         the wave of every workgroup that runs the serial parts adds its
  *                         shader-clock cycles by phase (load and checksum, chains, waiting for
  *                         the searches, decisions, symbols to scratch, the group's blocks by
- *                         lanes, stored bytes; last: objects done): tools/probe_deflate_phases.py
+ *                         lanes, stored bytes; last: objects done), and one searching wave of every workgroup its own to
+ *                         the other six: tools/probe_deflate_phases.py
  */
 #ifndef VIT_HASH_BENCH_H
 #define VIT_HASH_BENCH_H

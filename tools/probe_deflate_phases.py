@@ -22,16 +22,17 @@ if kind == "text":
     blobs = [text[int(s):int(s) + L] for s in starts]
 else:
     blobs = [rng.integers(0, 256, L, dtype=np.uint8).tobytes() for _ in range(n)]
-trace = h.alloc(64)
+trace = h.alloc(128)
 names = ["load+checksum", "chains", "waiting_for_searches", "decisions", "symbols_out", "blocks_by_lanes", "stored_copy"]
 got, dt = h.deflate_objects("blob", blobs)
-trace.upload(np.zeros(8, dtype=np.uint64))
+trace.upload(np.zeros(16, dtype=np.uint64))
 h.set_option("wave_trace_ptr", trace.ptr)
 got, dt = h.deflate_objects("blob", blobs)
 h.set_option("wave_trace_ptr", 0)
-t = trace.download(np.uint64, 64)
+t = trace.download(np.uint64, 128)
 bad = sum(1 for i in range(0, n, max(1, n // 500)) if got[i] != zlib.compress(b"blob %d\0" % L + blobs[i], 6))
 objs = max(int(t[7]), 1)
 print(json.dumps({"objects": n, "bytes_each": L, "content": kind, "seconds_in_call": round(dt, 4), "objects_per_s": round(n / dt, 1),
                   "cycles_per_object_by_phase": {k: int(t[i] // objs) for i, k in enumerate(names)},
-                  "cycles_per_object": int(t[:7].sum() // objs), "objects_traced": int(t[7]), "mismatches_in_sample": bad}))
+                  "cycles_per_object": int(t[:7].sum() // objs), "one_searching_wave_per_object": dict(zip(["cycles_handing_out", "cycles_after", "rounds_handing_out", "rounds_after", "cycles_at_tile_barriers", "entries_after"],
+                                                        [round(float(x) / objs, 1) for x in t[8:14]])), "objects_traced": int(t[7]), "mismatches_in_sample": bad}))

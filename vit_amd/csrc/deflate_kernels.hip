@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(DeflateBatch b, uint32_t on
 constexpr uint32_t kGroup = 32;                              // objects a workgroup scans before it writes their blocks
 constexpr uint32_t kRefill = 16;                            // searching lanes that must be free before the wave stops to hand out positions
 constexpr uint32_t kHopsInARow = 2;                         // chain entries a lane looks at between two comparisons
+constexpr uint32_t kHopsAtTheEnd = 8;                       // ... once the tile's positions are all handed out
 
 // A class's workgroup: threads, and positions per tile.  The two small classes fit a CU four times with four waves each;
 // of the large ones a CU holds two or one, which then have eight and sixteen waves and longer tiles to keep them busy.
@@ -228,6 +229,8 @@ __global__ __launch_bounds__(WaveClass<NMAX>::kThreads, WaveClass<NMAX>::kWavesP
     const zw::Chain chain{sh.entry, BKBITS, POSBITS};
     constexpr uint32_t kBuckets = 1u << BKBITS;
     uint64_t spent[8] = {0, 0, 0, 0, 0, 0, 0, 0};           // diagnostics: cycles by phase (DeflateBatch::trace)
+    uint64_t walking[6] = {0, 0, 0, 0, 0, 0};               // ... of one searching wave: cycles while positions are handed out, cycles after
+                                                            // (a tile's longest chains), rounds of either, cycles at the tiles' barriers, entries looked at after
     uint64_t mark = __builtin_readcyclecounter();
     auto lap = [&](int phase) { const uint64_t now = __builtin_readcyclecounter(); spent[phase] += now - mark; mark = now; };
 
@@ -360,7 +363,8 @@ __global__ __launch_bounds__(WaveClass<NMAX>::kThreads, WaveClass<NMAX>::kWavesP
                 zw::Found* const found = sh.found[t & 1u];
                 uint32_t* const grab = &sh.grab[t & 1u];
                 zw::Walk k;
-                bool holds = false, dry = false;             // holds: k's answer is not stored yet; dry: the tile has no position left
+                bool holds = false, dry = false, hurried = false;   // holds: k's answer is not stored yet; dry: the tile has no position left
+                uint64_t t_begin = __builtin_readcyclecounter(), t_dry = 0;
                 for (;;) {
                     const uint64_t done = __ballot(k.state == zw::Walk::kDone);
                     if (done == ~0ull || (!dry && __builtin_popcountll(done) >= int(kRefill))) {
@@ -379,11 +383,26 @@ __global__ __launch_bounds__(WaveClass<NMAX>::kThreads, WaveClass<NMAX>::kWavesP
                         }
                         if (__ballot(k.state != zw::Walk::kDone || holds) == 0) break;
                     }
+                    if (!dry) {
+                        ++walking[2];
 #pragma unroll
-                    for (uint32_t hop = 0; hop < kHopsInARow; ++hop)
-                        if (k.state == zw::Walk::kHop) zw::walk_hop(k, d, chain);
+                        for (uint32_t hop = 0; hop < kHopsInARow; ++hop)
+                            if (k.state == zw::Walk::kHop) zw::walk_hop(k, d, chain);
+                    } else {
+                        // The tile is handed out and ends with its longest chain: what is still walking goes entry by entry
+                        // in a loop of nothing else, ahead of the waves that have positions left to take.
+                        if (!hurried) { hurried = true; __builtin_amdgcn_s_setprio(2); t_dry = __builtin_readcyclecounter(); }
+                        ++walking[3];
+                        for (uint32_t hop = 0; hop < kHopsAtTheEnd && __ballot(k.state == zw::Walk::kHop) != 0; ++hop) {
+                            ++walking[5];
+                            if (k.state == zw::Walk::kHop) zw::walk_hop(k, d, chain);
+                        }
+                    }
                     if (k.state == zw::Walk::kCompare) zw::walk_compare(k, d);
                 }
+                if (hurried) __builtin_amdgcn_s_setprio(0);
+                const uint64_t t_end = __builtin_readcyclecounter();
+                if (t_dry) { walking[0] += t_dry - t_begin; walking[1] += t_end - t_dry; } else walking[0] += t_end - t_begin;
             };
             if (!serial) {
                 if (tile < tiles) search_tile(tile);
@@ -449,7 +468,9 @@ __global__ __launch_bounds__(WaveClass<NMAX>::kThreads, WaveClass<NMAX>::kWavesP
                 lap(3);
                 if (tile < tiles) search_tile(tile);         // and then it searches with the others
             }
+            const uint64_t t_arrive = __builtin_readcyclecounter();
             __syncthreads();
+            walking[4] += __builtin_readcyclecounter() - t_arrive;
             if (serial) lap(2);                             // (what the serial wave waited for the searches)
         }
         // ---- the symbols into zlib's form (a literal's byte is read only now) and their counts, a symbol per thread
@@ -489,6 +510,8 @@ __global__ __launch_bounds__(WaveClass<NMAX>::kThreads, WaveClass<NMAX>::kWavesP
     if (in_group) write_blocks(in_group);
     if (b.trace && serial && lane == 0)
         for (int k = 0; k < 8; ++k) if (spent[k]) atomicAdd(reinterpret_cast<unsigned long long*>(&b.trace[k]), (unsigned long long)spent[k]);
+    if (b.trace && wave == (serial_wave + 1u) % (kThreads / 64u) && lane == 0)
+        for (int k = 0; k < 6; ++k) if (walking[k]) atomicAdd(reinterpret_cast<unsigned long long*>(&b.trace[8 + k]), (unsigned long long)walking[k]);
 }
 
 uint64_t deflate_workspace_bytes(uint32_t lanes) { return (uint64_t)lanes * (zd::work_bytes() + zd::small_bytes()); }

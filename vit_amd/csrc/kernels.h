@@ -129,9 +129,11 @@ struct DeflateBatch {
     const void*     tables_raw;   // device copy of what deflate_make_tables() wrote
     uint32_t*       status;
     uint32_t        max_input;    // objects of more framed bytes are nobody's here (their out_len stays as it is)
-    uint64_t*       trace;        // diagnostics, normally nullptr: 8 counters the workgroup-per-object kernels add their serial wave's
-                                  // shader-clock cycles to, by phase (load + checksum, chains, waiting for the searches, decisions,
-                                  // symbols to scratch, the group's blocks by lanes, stored bytes; last: objects)
+    uint64_t*       trace;        // diagnostics, normally nullptr: 14 counters.  0-7: the workgroup-per-object kernels add their serial
+                                  // wave's shader-clock cycles by phase (load + checksum, chains, waiting for the searches, decisions,
+                                  // symbols to scratch, the group's blocks by lanes, stored bytes; last: objects).  8-13: one searching
+                                  // wave's cycles while a tile's positions are handed out and after, rounds of either, cycles at the
+                                  // tiles' barriers, chain entries looked at after the tile was handed out
 };
 uint64_t deflate_workspace_bytes(uint32_t lanes);
 uint64_t deflate_tables_bytes();

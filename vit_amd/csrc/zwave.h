@@ -57,17 +57,23 @@ ZD_FN uint32_t ctz32(uint32_t x) { return uint32_t(__builtin_ctz(x)); }
 
 // 4 (2) bytes from byte i of the message, byte i lowest: the two aligned dwords around them and a funnel shift.  (LDS
 // serves a load from any byte address, but a wave's unaligned load stalls it for tens of cycles: measured, four fifths
-// of the LDS's busy time went there.)  ld_pair: the two dwords, loaded where the call stands.
+// of the LDS's busy time went there.)
 struct Pair { uint32_t lo, hi; };
-ZD_FN Pair ld_pair(const uint32_t* d, uint32_t i)
-{
-    const volatile uint32_t* const p = d + (i >> 2);        // volatile: the compiler would otherwise move the loads into the branch that
-    return Pair{p[0], p[1]};                               // uses their value, and a wave would wait for its loads one after the other
-}
+// "These values are needed here": the compiler would otherwise move a load into the branch that uses its value, and a
+// wave would wait for its loads one after the other instead of once for all of them.  (Not `volatile`: on this target a
+// volatile load of LDS becomes a system-coherent FLAT load with a wait of its own, several times as slow.)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZW_LOADED_2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define ZW_LOADED_3(a, b, c) asm volatile("" : "+v"(a), "+v"(b), "+v"(c))
+#define ZW_LOADED_6(a, b, c, d, e, f) asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f))
+#else
+#define ZW_LOADED_2(a, b) ((void)0)
+#define ZW_LOADED_3(a, b, c) ((void)0)
+#define ZW_LOADED_6(a, b, c, d, e, f) ((void)0)
+#endif
 ZD_FN uint32_t from_pair(Pair v, uint32_t i) { return uint32_t((uint64_t(v.hi) << 32 | v.lo) >> ((i & 3u) * 8u)); }
 ZD_FN uint32_t ld32(const uint32_t* d, uint32_t i) { return from_pair(Pair{d[i >> 2], d[(i >> 2) + 1]}, i); }
 ZD_FN uint32_t ld16(const uint32_t* d, uint32_t i) { return ld32(d, i) & 0xffffu; }
-ZD_FN uint32_t ld_now(const uint16_t* p) { return *const_cast<const volatile uint16_t*>(p); }
 ZD_FN uint32_t byte_at(const uint32_t* d, uint32_t i) { return (d[i >> 2] >> ((i & 3u) * 8u)) & 0xffu; }
 
 // zlib's hash of the three bytes at a position (UPDATE_HASH three times: 15 bits, shift 5), from ld32 there.
@@ -133,8 +139,10 @@ ZD_FN void walk_begin(Walk& k, const uint32_t* d, uint32_t n, const Chain& c, ui
 ZD_FN void walk_hop(Walk& k, const uint32_t* d, const Chain& c)
 {
     // (both loads before anything is decided: one wait for the two, not one after the other)
-    const uint32_t e = ld_now(&c.entry[k.cur]), here = k.cur;
-    const uint32_t t = from_pair(ld_pair(d, here + k.best - 1), here + k.best - 1) & 0xffffu;
+    const uint32_t here = k.cur, at = here + k.best - 1;
+    uint32_t e = c.entry[here], lo = d[at >> 2], hi = d[(at >> 2) + 1];
+    ZW_LOADED_3(e, lo, hi);
+    const uint32_t t = from_pair(Pair{lo, hi}, at) & 0xffffu;
     k.cur = c.prev(e);
     if (c.high(e) == k.hh) {                                // same bucket and same high bits: one of zlib's candidates
         k.any = kAny;
@@ -150,9 +158,10 @@ ZD_FN void walk_compare(Walk& k, const uint32_t* d)
 {
     // eight bytes of each side: three aligned dwords around them
     const uint32_t pa = k.p + k.same, pc = k.cand + k.same;
-    const volatile uint32_t* const va = d + (pa >> 2);
-    const volatile uint32_t* const vc = d + (pc >> 2);
-    const uint32_t a0 = va[0], a1 = va[1], a2 = va[2], c0 = vc[0], c1 = vc[1], c2 = vc[2];
+    const uint32_t* const va = d + (pa >> 2);
+    const uint32_t* const vc = d + (pc >> 2);
+    uint32_t a0 = va[0], a1 = va[1], a2 = va[2], c0 = vc[0], c1 = vc[1], c2 = vc[2];
+    ZW_LOADED_6(a0, a1, a2, c0, c1, c2);
     const uint32_t x0 = from_pair(Pair{a0, a1}, pa) ^ from_pair(Pair{c0, c1}, pc), x1 = from_pair(Pair{a1, a2}, pa) ^ from_pair(Pair{c1, c2}, pc);
     if ((x0 | x1) == 0) { k.same += 8; if (k.same < uint32_t(zd::kMaxMatch)) return; }
     uint32_t len = x0 ? k.same + (ctz32(x0) >> 3) : x1 ? k.same + 4 + (ctz32(x1) >> 3) : k.same;
