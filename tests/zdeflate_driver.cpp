@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     std::vector<uint16_t> head(zd::kHashSize * 3), prev(32768 * 3), dbuf(zd::kLitBufSize * 3);
     std::vector<uint8_t> lbuf(zd::kLitBufSize * 3);
     std::vector<uint16_t> small(zd::kSmallEntries * 5);
-    std::vector<uint32_t> heap(zd::kHeapEntries * 5);
+    std::vector<uint32_t> heap(zd::kHeapEntries * 5), heap_low(2 * 288 + 2);
     std::mt19937_64 rng(atoi(argc > 2 ? argv[2] : "777"));
     static zd::Deflater<PtrIn> d;
     int bad = 0; size_t total = 0;
@@ -70,6 +70,9 @@ int main(int argc, char** argv) {
         std::fill(head.begin(), head.end(), 0);
         const uint32_t st = r % 2 ? 3 : 1;                     // the arrays strided as the GPU lanes interleave theirs, and plain
         zd::Work w{{head.data(), st}, {prev.data(), st}, {dbuf.data(), st}, {lbuf.data(), st}, small.data() + (r % 3), heap.data() + (r % 4), uint32_t(r % 2 ? 5 : 1), out.data(), uint32_t(out.size())};
+        if (r % 3 == 0) {                                       // the Huffman heap in two places, as the GPU's block writer keeps it
+            w.heap = heap_low.data() + (r % 2); w.heap_stride = 2; w.heap_high = heap.data() + (r % 4); w.heap_split = r % 2 ? 288 : 40;
+        }
         d.in = PtrIn{in.data(), n};
         uint32_t got = d.run(&t, w, n);
         total += n;

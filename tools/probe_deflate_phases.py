@@ -23,7 +23,7 @@ if kind == "text":
 else:
     blobs = [rng.integers(0, 256, L, dtype=np.uint8).tobytes() for _ in range(n)]
 trace = h.alloc(128)
-names = ["load+checksum", "chains", "waiting_for_searches", "decisions", "symbols_out", "blocks_by_lanes", "stored_copy"]
+names = ["load+checksum", "chains", "waiting_for_searches", "decisions", "symbols_out", "trees_by_lanes", "block_content"]
 got, dt = h.deflate_objects("blob", blobs)
 trace.upload(np.zeros(16, dtype=np.uint64))
 h.set_option("wave_trace_ptr", trace.ptr)

@@ -131,6 +131,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(DeflateBatch b, uint32_t on
 // What bounds it (text-like 4 KiB objects, 1.5 M/s): a tile is done when its longest chain is, entry by entry at
 // some 900 clocks an entry in a wave that shares its SIMD with three others; the VALUs are busy 40 % of the time.
 constexpr uint32_t kGroup = 32;                              // objects a workgroup scans before it writes their blocks
+constexpr uint32_t kHeapInLds = zd::kLCodes + 2;            // entries of a Huffman heap kept in LDS: all that are ever sifted (at most one per code)
 constexpr uint32_t kRefill = 16;                            // searching lanes that must be free before the wave stops to hand out positions
 constexpr uint32_t kHopsInARow = 2;                         // chain entries a lane looks at between two comparisons
 constexpr uint32_t kHopsAtTheEnd = 8;                       // ... once the tile's positions are all handed out
@@ -162,11 +163,12 @@ template <int NMAX, int BKBITS> struct WaveShared {
 
 // A workgroup's scratch in device memory: kGroup slots of symbols, the kGroup objects' tree arrays interleaved
 // (entry e of slot s at e * kGroup + s: the lanes that build the trees read the same entry of their own arrays
-// together), and a few words per slot.
+// together; the construction's heap is in LDS), and a few words per slot.
 template <int NMAX> struct WaveScratch {
     static constexpr uint64_t kSymBytes = (3ull * (NMAX + 2) + 15) / 16 * 16;
-    static constexpr uint64_t kSmallBytes = 2ull * zd::kSmallEntries * kGroup, kHeapBytes = 4ull * zd::kHeapEntries * kGroup;
-    static constexpr uint32_t kMetaWords = 8;                // per slot: object (2), length, symbols, checksum, where a stored block's bytes go
+    static constexpr uint64_t kSmallBytes = 2ull * zd::kSmallEntries * kGroup;
+    static constexpr uint64_t kHeapBytes = 4ull * (zd::kHeapEntries - kHeapInLds) * kGroup;   // the heap's entries that are not in LDS
+    static constexpr uint32_t kMetaWords = 8;                // per slot: object (2), length, symbols, checksum, and what begin_block_by_lane leaves (3)
     static constexpr uint64_t kMetaBytes = 4ull * kMetaWords * kGroup;
     static constexpr uint64_t kBytes = (kGroup * kSymBytes + kSmallBytes + kHeapBytes + kMetaBytes + 255) / 256 * 256;
 };
@@ -183,22 +185,26 @@ __device__ __forceinline__ void bump_lds(uint16_t* e)
                            __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// One object's block by one lane: the trees from the symbols' counts, the block's head and its codes (zdeflate.h's code
-// as it is), the checksum the scan worked out.  A block that zlib stores is left to the caller: meta[5] = where its
-// bytes go.  Not inlined: its registers are its own, the scan's loops keep theirs.
+// One object's block as far as one lane must make it: the trees from the symbols' counts and the block's head
+// (zdeflate.h's code as it is).  The heap of the Huffman construction, its one array that is read and written at
+// every step of a long dependent chain, is the caller's to place (its low entries, the part that is sifted, in LDS, the
+// rest with the tree arrays in the scratch).  What
+// follows the head is left to the workgroup: meta[5] = where a stored block's bytes go (else 0), meta[6] = bytes of the
+// stream so far, meta[7] = the bits not yet in them (value, count << 16) and the block's kind << 24.  Not inlined: its
+// registers are its own, the scan's loops keep theirs.
 template <int NMAX>
-__device__ __attribute__((noinline)) void write_block_by_lane(const DeflateBatch& b, const zd::Tables* tables, uint8_t* sym, uint16_t* small,
-                                                              uint32_t* heap, uint32_t* meta)
+__device__ __attribute__((noinline)) void begin_block_by_lane(const DeflateBatch& b, const zd::Tables* tables, uint8_t* sym, uint16_t* small,
+                                                              uint32_t* heap, uint32_t heap_stride, uint32_t* heap_high, uint32_t* meta)
 {
     const uint64_t i = ((uint64_t)meta[1] << 32) | meta[0];
-    const uint32_t n = meta[2], adler = meta[4];
+    const uint32_t n = meta[2];
     zd::Deflater<ArenaBytes> df;
     df.in = ArenaBytes{b.arena + b.offsets[i]};
     zd::Work w;
     w.head = zd::Arr16{nullptr, 1}; w.prev = zd::Arr16{nullptr, 1};
     w.d_buf = zd::Arr16{reinterpret_cast<uint16_t*>(sym), 1};
     w.l_buf = zd::Arr8{sym + 2u * (NMAX + 2), 1};
-    w.small = small; w.heap = heap; w.small_stride = kGroup;
+    w.small = small; w.heap = heap; w.small_stride = kGroup; w.heap_stride = heap_stride; w.heap_high = heap_high; w.heap_split = kHeapInLds;
     w.out = b.out + b.out_off[i];
     w.out_cap = zd::bound(n);
     df.setup(tables, w, n);
@@ -206,19 +212,25 @@ __device__ __attribute__((noinline)) void write_block_by_lane(const DeflateBatch
     df.s.last_lit = meta[3];
     const int kind = df.plan_block(n);
     df.emit_block_head(kind, n, 1);
-    uint32_t stored_at = 0;
-    if (kind == zd::Deflater<ArenaBytes>::kStored) { stored_at = df.s.pending; df.s.pending += n; if (df.s.pending > w.out_cap) df.s.overflow = true; }
-    else { df.compress_block(kind == zd::Deflater<ArenaBytes>::kFixed); df.bi_windup(); }
-    df.put_byte(adler >> 24); df.put_byte((adler >> 16) & 0xffu); df.put_byte((adler >> 8) & 0xffu); df.put_byte(adler & 0xffu);
-    b.out_len[i] = df.s.overflow ? 0u : df.s.pending;
-    meta[5] = df.s.overflow ? 0u : stored_at;
+    meta[5] = kind == zd::Deflater<ArenaBytes>::kStored ? df.s.pending : 0u;
+    meta[6] = df.s.overflow ? ~0u : df.s.pending;
+    meta[7] = uint32_t(df.s.bi_buf) | uint32_t(df.s.bi_valid) << 16 | uint32_t(kind) << 24;
 }
+
+// What the workgroup keeps in LDS while it writes a block's content (in place of everything the scan kept there).
+template <int NMAX, int THREADS> struct EmitShared {
+    uint32_t lit[zd::kLCodes + 2];                          // literal/length codes: code | bits << 16
+    uint32_t dist[zd::kDCodes + 2];                         // distance codes likewise
+    uint32_t waves[THREADS / 64 + 1];                       // bits of each wave's symbols, for the running sum
+    uint32_t out[(NMAX + 64) / 4 + 4];                      // the block's content from the stream's current byte on
+};
 
 template <int NMAX, int BKBITS, int POSBITS>
 __global__ __launch_bounds__(WaveClass<NMAX>::kThreads, WaveClass<NMAX>::kWavesPerSimd) void deflate_wave_kernel(DeflateBatch b, uint32_t n_above)
 {
     constexpr uint32_t kThreads = WaveClass<NMAX>::kThreads, kScanTile = WaveClass<NMAX>::kTile;
-    __shared__ WaveShared<NMAX, BKBITS> sh;
+    using Shared = WaveShared<NMAX, BKBITS>;
+    __shared__ Shared sh;
     using Scratch = WaveScratch<NMAX>;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const zd::Tables* const tables = static_cast<const zd::Tables*>(b.tables_raw);
@@ -248,24 +260,108 @@ __global__ __launch_bounds__(WaveClass<NMAX>::kThreads, WaveClass<NMAX>::kWavesP
     const uint32_t serial_wave = sh.elect & 15u;
     const bool serial = wave == serial_wave;
 
-    // One lane per object of the group: the trees, the block's head and its codes, zdeflate.h's code as it is.  A block
-    // that zlib stores (content no code shortens) has its bytes copied by all threads afterwards.
+    // The blocks of a group of objects.  First one lane per object: the trees and the block's head (a Huffman
+    // construction is a chain of dependent accesses that lanes cannot share but can each have one of), as many lanes at
+    // a time as LDS has room for their heaps.  Then object by object all threads: a stored block's bytes copied; else
+    // every symbol's code and extra bits (compress_block of trees.c), each thread a run of symbols, placed by a running
+    // sum of their lengths and OR-ed into LDS, then the content, the checksum and the length to their places.
     constexpr uint32_t kMeta = Scratch::kMetaWords;
+    constexpr uint32_t kHeapRoom = uint32_t(offsetof(Shared, grab)) / (4u * kHeapInLds);
+    constexpr uint32_t kHeapLanes = kHeapRoom >= 32 ? 32 : kHeapRoom >= 16 ? 16 : 8;
+    static_assert(kHeapRoom >= 8, "LDS holds the heaps of eight lanes at least");
+    static_assert(sizeof(EmitShared<NMAX, WaveClass<NMAX>::kThreads>) <= offsetof(Shared, grab), "the block's content fits where the scan's arrays were");
     auto write_blocks = [&](uint32_t count) {
         __syncthreads();
-        if (serial && lane < count)
-            write_block_by_lane<NMAX>(b, tables, scratch + (uint64_t)lane * Scratch::kSymBytes, g_small + lane, g_heap + lane, g_meta + lane * kMeta);
+        if (serial) {
+            uint32_t* const heaps = reinterpret_cast<uint32_t*>(&sh);
+            for (uint32_t first = 0; first < count; first += kHeapLanes) {
+                const uint32_t slot = first + lane;
+                if (lane < kHeapLanes && slot < count)
+                    begin_block_by_lane<NMAX>(b, tables, scratch + (uint64_t)slot * Scratch::kSymBytes, g_small + slot, heaps + lane, kHeapLanes, g_heap + slot,
+                                              g_meta + slot * kMeta);
+            }
+        }
         __syncthreads();
         lap(5);
+        auto& em = *reinterpret_cast<EmitShared<NMAX, WaveClass<NMAX>::kThreads>*>(&sh);
         for (uint32_t k = 0; k < count; ++k) {
             const uint32_t* const meta = g_meta + k * kMeta;
-            const uint32_t stored_at = meta[5];
-            if (stored_at == 0) continue;
             const uint64_t i = ((uint64_t)meta[1] << 32) | meta[0];
-            const uint32_t n = meta[2];
-            const uint8_t* const from = b.arena + b.offsets[i];
-            uint8_t* const to = b.out + b.out_off[i] + stored_at;
-            for (uint32_t j = tid; j < n; j += kThreads) to[j] = from[j ^ 3u];
+            const uint32_t n = meta[2], n_sym = meta[3], adler = meta[4], stored_at = meta[5], pending = meta[6];
+            const uint32_t kind = meta[7] >> 24, held = meta[7] & 0xffffu, held_bits = (meta[7] >> 16) & 0xffu;
+            uint8_t* const stream = b.out + b.out_off[i];
+            if (pending == ~0u) { if (tid == 0) b.out_len[i] = 0; continue; }       // (no room: cannot happen within the bound)
+            if (stored_at) {
+                const uint8_t* const from = b.arena + b.offsets[i];
+                for (uint32_t j = tid; j < n; j += kThreads) stream[stored_at + j] = from[j ^ 3u];
+                if (tid == 0) {
+                    uint8_t* const end = stream + stored_at + n;
+                    end[0] = uint8_t(adler >> 24); end[1] = uint8_t(adler >> 16); end[2] = uint8_t(adler >> 8); end[3] = uint8_t(adler);
+                    b.out_len[i] = stored_at + n + 4u;
+                }
+                continue;
+            }
+            // the codes into LDS (a fixed block's from the tables, a dynamic block's from the trees the lane built)
+            const bool fixed = kind == uint32_t(zd::Deflater<ArenaBytes>::kFixed);
+            for (uint32_t e = tid; e < uint32_t(zd::kLCodes); e += kThreads)
+                em.lit[e] = fixed ? uint32_t(tables->static_lcode[e]) | uint32_t(tables->static_llen[e]) << 16
+                                  : uint32_t(g_small[e * kGroup + k]) | uint32_t(g_small[(zd::kLtN + e) * kGroup + k]) << 16;
+            if (tid < uint32_t(zd::kDCodes))
+                em.dist[tid] = fixed ? uint32_t(tables->static_dcode[tid]) | 5u << 16
+                                     : uint32_t(g_small[(2u * zd::kLtN + tid) * kGroup + k]) | uint32_t(g_small[(2u * zd::kLtN + zd::kDtN + tid) * kGroup + k]) << 16;
+            for (uint32_t w = tid; w < uint32_t(sizeof(em.out) / 4); w += kThreads) em.out[w] = 0;
+            __syncthreads();
+            // a symbol's bits, low bit first: code, extra length bits, distance code, extra distance bits (at most 48)
+            const uint16_t* const d_buf = reinterpret_cast<const uint16_t*>(scratch + (uint64_t)k * Scratch::kSymBytes);
+            const uint8_t* const l_buf = scratch + (uint64_t)k * Scratch::kSymBytes + 2u * (NMAX + 2);
+            auto bits_of = [&](uint32_t at, uint32_t& count_out) -> uint64_t {
+                const uint32_t dist = d_buf[at], lc = l_buf[at];
+                if (dist == 0) { const uint32_t c = em.lit[lc]; count_out = c >> 16; return c & 0xffffu; }
+                const uint32_t lcode = zd::length_code_of(lc), c = em.lit[lcode + zd::kLiterals + 1];
+                uint64_t v = c & 0xffffu;
+                uint32_t have = c >> 16;
+                if (lcode >= 8 && lcode < 28) { const uint32_t extra = (lcode >> 2) - 1u; v |= uint64_t(lc & ((1u << extra) - 1u)) << have; have += extra; }
+                const uint32_t dm = dist - 1u, dcode = zd::dist_code_of(dm), dc = em.dist[dcode];
+                v |= uint64_t(dc & 0xffffu) << have; have += dc >> 16;
+                if (dcode >= 4) { const uint32_t extra = (dcode >> 1) - 1u; v |= uint64_t(dm & ((1u << extra) - 1u)) << have; have += extra; }
+                count_out = have;
+                return v;
+            };
+            const uint32_t each = (n_sym + kThreads - 1u) / kThreads, from = tid * each, upto = from + each < n_sym ? from + each : n_sym;
+            uint32_t mine = 0;
+            for (uint32_t at = from; at < upto; ++at) { uint32_t c; (void)bits_of(at, c); mine += c; }
+            // where this thread's run begins: the running sum over the threads before it
+            uint32_t before = mine;
+#pragma unroll
+            for (uint32_t step = 1; step < 64; step <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)before, step); if (lane >= step) before += up; }
+            if (lane == 63) em.waves[wave] = before;
+            __syncthreads();
+            uint32_t position = held_bits + before - mine, all_bits = held_bits;
+            for (uint32_t w = 0; w < kThreads / 64u; ++w) { const uint32_t t = em.waves[w]; if (w < wave) position += t; all_bits += t; }
+            auto put = [&](uint64_t v, uint32_t at_bit) {
+                const uint32_t word = at_bit >> 5, shift = at_bit & 31u;
+                const uint64_t low = v << shift;
+                const uint32_t w0 = uint32_t(low), w1 = uint32_t(low >> 32), w2 = shift ? uint32_t(v >> (64u - shift)) : 0u;
+                if (w0) atomicOr(&em.out[word], w0);
+                if (w1) atomicOr(&em.out[word + 1u], w1);
+                if (w2) atomicOr(&em.out[word + 2u], w2);
+            };
+            if (tid == 0) put(held, 0);                      // the head's last bits, which the lane had not yet written
+            for (uint32_t at = from; at < upto; ++at) { uint32_t c; const uint64_t v = bits_of(at, c); put(v, position); position += c; }
+            if (tid == 0) { const uint32_t c = em.lit[zd::kEndBlock]; put(c & 0xffffu, all_bits); }
+            __syncthreads();
+            const uint32_t content = (all_bits + (em.lit[zd::kEndBlock] >> 16) + 7u) >> 3;      // bi_windup: to a whole byte
+            const bool fits = pending + content + 4u <= zd::bound(n);
+            if (fits) {
+                const uint8_t* const made = reinterpret_cast<const uint8_t*>(em.out);
+                for (uint32_t j = tid; j < content; j += kThreads) stream[pending + j] = made[j];
+                if (tid == 0) {
+                    uint8_t* const end = stream + pending + content;
+                    end[0] = uint8_t(adler >> 24); end[1] = uint8_t(adler >> 16); end[2] = uint8_t(adler >> 8); end[3] = uint8_t(adler);
+                }
+            }
+            if (tid == 0) b.out_len[i] = fits ? pending + content + 4u : 0u;
+            __syncthreads();                                // the next object's codes replace these
         }
         __syncthreads();
         lap(6);

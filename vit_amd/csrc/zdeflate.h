@@ -180,9 +180,13 @@ ZD_FN void counts_settled()
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
 #endif
 }
+// (An array in two places: entries below `split` at p, the others at p_high.  The heap of the Huffman construction is
+// one: the part that is sifted, a long chain of dependent accesses, is its low entries, and a caller may have fast
+// memory for those only.)
 struct Arr32 {
     uint32_t* p; uint32_t stride;
-    ZD_FN uint32_t& operator[](int i) const { return p[uint32_t(i) * stride]; }
+    uint32_t* p_high = nullptr; uint32_t stride_high = 0; uint32_t split = ~0u;
+    ZD_FN uint32_t& operator[](int i) const { return uint32_t(i) < split ? p[uint32_t(i) * stride] : p_high[(uint32_t(i) - split) * stride_high]; }
 };
 struct Arr8 {
     uint8_t* p; uint32_t stride;
@@ -206,6 +210,9 @@ struct Work {
     uint32_t  small_stride;
     uint8_t*  out;                           // the stream; capacity out_cap
     uint32_t  out_cap;
+    uint32_t  heap_stride = 0;               // of `heap`, if other than small_stride (a caller may keep the heap elsewhere)
+    uint32_t* heap_high = nullptr;           // if set: entries from heap_split on are here, small_stride apart (entry heap_split first)
+    uint32_t  heap_split = ~0u;
 };
 
 constexpr uint32_t work_bytes() { return kHashSize * 2 + 32768 * 2 + kLitBufSize * 2 + kLitBufSize; }
@@ -554,7 +561,7 @@ template <class In> struct Deflater {
         s.dt_fc = take(kDtN); s.dt_dl = take(kDtN);
         s.bt_fc = take(kBtN); s.bt_dl = take(kBtN);
         s.bl_count = take(16); s.next_code = take(16);
-        s.heap = Arr32{work.heap, st};
+        s.heap = Arr32{work.heap, work.heap_stride ? work.heap_stride : st, work.heap_high, st, work.heap_high ? work.heap_split : ~0u};
         s.opt_len = s.static_len = 0;
         s.last_lit = 0;
     }
