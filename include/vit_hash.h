@@ -267,10 +267,11 @@ int vit_bin_order_device(vit_hasher *h, int dev, const uint32_t *d_nblocks, uint
  * block; the default "deflate_max_bytes") is deflated by one WORKGROUP with the
  * object, its hash chains and the block's symbols in LDS: one wave builds the
  * chains and runs zlib's decisions, the others walk the chains of the positions
- * ahead of it; the blocks of 32 objects at a time are then written one per lane
- * (Huffman trees, codes, bits).  Device memory sees the object once, its symbols
- * and tree arrays in a scratch of the workgroups in flight (0.64 GB per queue,
- * allocated on first use and kept), and its stream once.  With
+ * ahead of it; for 32 objects at a time the Huffman trees are then built one
+ * object per lane and the blocks' bits written by all threads.  Device memory
+ * sees the object once, its symbols and tree arrays in a scratch of the
+ * workgroups in flight (0.6 GB per queue, allocated on first use and kept), and
+ * its stream once.  With
  * "deflate_max_bytes" raised (at most 65536, the range in which zlib's window
  * never slides) the longer objects are deflated one per LANE with 181 KiB of
  * tables each in device memory, which the library then allocates for
