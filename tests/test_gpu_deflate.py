@@ -54,6 +54,52 @@ def test_device_streams_equal_zlibs_for_every_kind_of_content(hasher):
     assert hasher.device_status() == 0
 
 
+def _content_for_framed_length(target, type_="blob"):
+    """Length of the content whose framed object (type, length in decimal, NUL, content) has exactly `target` bytes;
+    None where no length gives it (one more digit in the header skips a value)."""
+    for digits in range(1, 7):
+        L = target - (len(type_) + 1 + digits + 1)
+        if L >= 0 and len(str(L)) == digits:
+            return L
+    return None
+
+
+def test_objects_at_the_edges_of_the_size_classes_and_of_the_tiles(hasher):
+    """Framed lengths at and around what separates the workgroup kernels' four size classes (1536, 4608, 9216, 16382),
+    the one-per-lane kernel behind them (16383) and the tiles the positions are searched in (512, 1024, 2048 and
+    their multiples), the last 15 positions (searched by zlib's own loop) and the shortest objects, with contents
+    that make the longest chains (one byte repeated, a period of three, a four-letter alphabet), none at all
+    (random) and ordinary ones (words)."""
+    rng = np.random.default_rng(77)
+    words = [b"the ", b"quick ", b"brown ", b"fox ", b"return ", b"void ", b"\n", b"    ", b"for (", b"}", b"const "]
+    edges = [1536, 4608, 9216, 16382]
+    framed_lengths = sorted({e + k for e in edges for k in (-17, -16, -15, -2, -1, 0, 1, 2, 15, 16, 17)} |
+                            {t * m + k for t in (512, 1024, 2048) for m in (1, 2, 3, 7) for k in (-16, -1, 0, 1, 16)} |
+                            set(range(7, 40)) | {16383, 16384, 16400})
+    blobs = []
+    for target in framed_lengths:
+        L = _content_for_framed_length(target)
+        if L is None:
+            continue
+        blobs += [rng.integers(0, 256, L, dtype=np.uint8).tobytes(),
+                  b"".join(words[int(k)] for k in rng.integers(0, len(words), L // 2 + 1))[:L],
+                  bytes([int(rng.integers(0, 256))]) * L,
+                  (b"abc" * (L // 3 + 1))[:L],
+                  (rng.integers(0, 4, L, dtype=np.uint8) + 97).tobytes()]
+    hasher.set_option("deflate_max_bytes", 65536)
+    try:
+        got, _ = hasher.deflate_objects("blob", blobs)
+    finally:
+        hasher.set_option("deflate_max_bytes", 16382)
+    for d, z in zip(blobs, got):
+        assert z == zlib.compress(_framed("blob", d), 6), (len(d), d[:12])
+    got, _ = hasher.deflate_objects("blob", blobs)               # the default limit: what is beyond one block is the caller's
+    for d, z in zip(blobs, got):
+        framed = _framed("blob", d)
+        assert z == (zlib.compress(framed, 6) if len(framed) <= 16382 else b""), len(d)
+    assert hasher.device_status() == 0
+
+
 def test_device_resident_arena_streams_and_the_files_they_make(hasher):
     """vit_deflate_arena_device on 100,000 synthetic 4 KiB blobs resident in HBM, in order of length and without:
     sampled streams equal zlib's and inflate to header + content."""

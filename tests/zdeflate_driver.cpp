@@ -38,7 +38,11 @@ int main(int argc, char** argv) {
         uint32_t n;
         switch (rng() % 8) { case 0: n = rng() % 40; break; case 1: n = rng() % 700; break; case 2: n = 4000 + rng() % 300; break;
             case 3: n = 16000 + rng() % 1000; break; case 4: n = 32700 + rng() % 200; break; case 5: n = 65536 - rng() % 3; break; default: n = rng() % 65537; }
-        if (wave_only) { switch (rng() % 7) { case 0: n = rng() % 64; break; case 1: n = 4000 + rng() % 700; break; case 2: n = 9000 + rng() % 300; break; case 3: n = zw::kMaxInput - rng() % 40; break; default: n = rng() % 9300; } }
+        if (wave_only) {
+            static const uint32_t edges[] = {512, 1024, 1536, 2048, 4096, 4608, 9216};     // tiles and size classes of the kernels
+            switch (rng() % 8) { case 0: n = rng() % 64; break; case 1: n = 4000 + rng() % 700; break; case 2: n = 9000 + rng() % 300; break;
+                case 3: n = zw::kMaxInput - rng() % 40; break; case 4: n = edges[rng() % 7] - 17 + rng() % 35; break; default: n = rng() % 9300; }
+        }
         std::vector<uint8_t> in(n + 1);
         int kind = rng() % 7;
         if (kind == 0) for (auto& b : in) b = uint8_t(rng());

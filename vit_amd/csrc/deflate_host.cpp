@@ -221,8 +221,11 @@ int vit_deflate_objects(vit_hasher* h, const char* type, const uint8_t* const* d
         b.arena = s.d_arena; b.arena_bytes = bytes; b.offsets = s.d_off; b.nblocks = s.d_nb; b.n = uint32_t(cnt);
         b.order = binned ? s.d_order : nullptr;
         b.out = z.d_out; b.out_off = d_zoff; b.out_len = d_zlen;
-        bool long_ones = false;                            // any object of this chunk beyond what a wave takes?
-        for (uint64_t k = 0; k < cnt && !long_ones; ++k) long_ones = uint64_t(s.h_nb[k]) * 64u > uint64_t(vit::deflate_wave_max_input()) + 9u + 63u;
+        bool long_ones = false;                            // any object of this chunk beyond what a workgroup takes?  (By its framed
+        for (uint64_t k = 0; k < cnt && !long_ones; ++k) { // length: the block count is the same for the 57 lengths around the limit.)
+            const uint64_t i = mine[pos + k];
+            long_ones = tl + 1 + vit::decimal_digits(len[i]) + 1 + len[i] > vit::deflate_wave_max_input();
+        }
         if (int rc = launch_both(h, q, b, long_ones, stream)) return rc;
         HIP_TRY(h, hipMemcpyAsync(direct ? out + out_lo : z.h_out, z.d_out, out_hi - out_lo, hipMemcpyDeviceToHost, stream));
         HIP_TRY(h, hipMemcpyAsync(h_zlen, d_zlen, cnt * 4, hipMemcpyDeviceToHost, stream));
