@@ -101,7 +101,7 @@ def test_stored_objects_are_byte_identical_to_the_oracles(oracle, golden_trees, 
 
 
 def test_device_deflate_stores_the_files_the_library_would(oracle, golden_trees, worktrees, tmp_path):
-    """The streams the GPU lanes write (forced onto small batches here; by default only batches of 16384 small objects
+    """The streams the GPU lanes write (forced onto small batches here; by default only batches of 4096 small objects
     and more take that way) are the zlib library's: every loose-object file of a worktree equals the oracle's, for the
     10,000-file skewed worktree (objects above the device's size limit go to host threads within the same batch), the
     1,000-file one and the one with odd names; and with the device path off the files are the same again."""

@@ -811,11 +811,10 @@ std::string ObjectStore::writeTree(const std::string& directoryPath)
     // A batch's contents live in one of three slots until its objects are stored.
     // With the device deflating there is a fourth stage (streams of batch k on the GPU, through a hasher and a
     // thread of its own, while this thread reads and hashes batch k+1), hence a fourth slot.  Whether a batch goes
-    // that way is decided batch by batch: the kernel needs tens of thousands of small objects to fill the chip (a
-    // launch lasts as long as its longest object on one lane, about 10 us per byte), fewer are done sooner by the
-    // host threads.
+    // that way is decided batch by batch: the kernels take one object per workgroup, a thousand of which are on the
+    // chip at a time, so a few thousand small objects keep it busy; fewer are done sooner by the host threads.
     const bool may_device = tree_side_ == Side::GPU && device_deflate_ && store_ && (deflate_level_ == -1 || deflate_level_ == 6);
-    uint64_t device_min_objects = 16384, device_max_bytes = 16382;     // up to there a wave deflates an object in LDS, no device tables
+    uint64_t device_min_objects = 4096, device_max_bytes = 16382;      // up to there a workgroup deflates an object in LDS, no device tables
     if (const char* e = std::getenv("VIT_DEVICE_DEFLATE_MIN")) device_min_objects = std::strtoull(e, nullptr, 10);
     if (const char* e = std::getenv("VIT_DEVICE_DEFLATE_MAX")) device_max_bytes = std::strtoull(e, nullptr, 10);
     const size_t ns = may_device ? 4 : 3;
