@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Where a wave of the wave-per-object deflate kernel spends its cycles: the kernels add their shader-clock cycles by
-phase, as thread 0 of every workgroup sees them, to a buffer the "wave_trace_ptr" option names (load + checksum, chains,
-searches, decisions, symbols to scratch, the group's blocks by lanes, stored bytes; last: objects done).
+"""Where a workgroup of the workgroup-per-object deflate kernels spends its cycles.  While the "wave_trace_ptr" option
+names a buffer of 128 bytes, the wave of every workgroup that runs the serial parts adds its shader-clock cycles by
+phase to its first eight counters (load + checksum, chains, waiting for the searches, decisions, symbols to scratch,
+trees by lanes, block content; last: objects done), and one searching wave of every workgroup adds what it did to the
+next six (cycles while a tile's positions are handed out and after, rounds of either, cycles at the tiles' barriers,
+chain entries looked at after the tile was handed out).  Printed per object.
     python tools/probe_deflate_phases.py [n] [len] [random|text]"""
 import json, os, sys, zlib
 import numpy as np
