@@ -155,6 +155,7 @@ template <int NMAX, int BKBITS> struct WaveShared {
     zw::Found found[2][kScanTile];                          // the searches' answers for the positions of two tiles
     uint32_t grab[2];                                       // per tile: how many of its positions have been handed out
     uint16_t lt_fc[zd::kLCodes + 2], dt_fc[zd::kDCodes + 2];   // the symbols' counts
+    unsigned long long trace[14];                           // diagnostics (DeflateBatch::trace), here and not in registers: the loops need those
     uint32_t n_sym;                                         // the scan's symbols, for the waves that do not run it
     uint32_t elect;                                         // which wave runs the serial parts
     uint32_t sum_a;                                         // the checksum's two sums before their reduction
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(WaveClass<NMAX>::kThreads, WaveClass<NMAX>::kWavesP
     __shared__ Shared sh;
     using Scratch = WaveScratch<NMAX>;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    bool laps = false;                                      // this wave's phases are the ones traced
     const zd::Tables* const tables = static_cast<const zd::Tables*>(b.tables_raw);
     uint8_t* const scratch = b.workspace + (uint64_t)blockIdx.x * Scratch::kBytes;
     uint16_t* const g_small = reinterpret_cast<uint16_t*>(scratch + kGroup * Scratch::kSymBytes);
@@ -240,17 +242,24 @@ __global__ __launch_bounds__(WaveClass<NMAX>::kThreads, WaveClass<NMAX>::kWavesP
     uint32_t* const g_meta = reinterpret_cast<uint32_t*>(scratch + kGroup * Scratch::kSymBytes + Scratch::kSmallBytes + Scratch::kHeapBytes);
     const zw::Chain chain{sh.entry, BKBITS, POSBITS};
     constexpr uint32_t kBuckets = 1u << BKBITS;
-    uint64_t spent[8] = {0, 0, 0, 0, 0, 0, 0, 0};           // diagnostics: cycles by phase (DeflateBatch::trace)
-    uint64_t walking[6] = {0, 0, 0, 0, 0, 0};               // ... of one searching wave: cycles while positions are handed out, cycles after
-                                                            // (a tile's longest chains), rounds of either, cycles at the tiles' barriers, entries looked at after
-    uint64_t mark = __builtin_readcyclecounter();
-    auto lap = [&](int phase) { const uint64_t now = __builtin_readcyclecounter(); spent[phase] += now - mark; mark = now; };
+    // Diagnostics (DeflateBatch::trace, normally off): cycles by phase as the serial wave sees them, and what one searching
+    // wave does.  Kept in LDS and touched at the phases' ends only: as arrays in registers they were spilled in every loop.
+    const bool tracing = b.trace != nullptr;
+    uint64_t mark = tracing ? __builtin_readcyclecounter() : 0;
+    auto count = [&](int slot, uint64_t v) { if (tracing && lane == 0) sh.trace[slot] += v; };
+    auto lap = [&](int phase) {                             // (the serial wave's: set once it is known which wave that is)
+        if (!tracing) return;
+        const uint64_t now = __builtin_readcyclecounter();
+        if (laps && lane == 0) sh.trace[phase] += now - mark;
+        mark = now;
+    };
 
     // One wave of the four runs what is serial (the chains, the decisions, the group's blocks).  A CU holds several
     // workgroups and gives each of them one wave on every SIMD, in the same wave slot: the wave whose SIMD number is
     // its slot's (mod 4) is the serial one, so that the workgroups of a CU have theirs on different SIMDs.  (Where
     // waves land is the hardware's to say: the election below yields exactly one wave whatever it says.)
     if (tid == 0) sh.elect = ~0u;
+    if (tid < 14) sh.trace[tid] = 0;
     __syncthreads();
     {
         const uint32_t hw = (uint32_t)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID: wave slot [3:0], SIMD [5:4]
@@ -259,6 +268,8 @@ __global__ __launch_bounds__(WaveClass<NMAX>::kThreads, WaveClass<NMAX>::kWavesP
     __syncthreads();
     const uint32_t serial_wave = sh.elect & 15u;
     const bool serial = wave == serial_wave;
+    const bool reports = wave == (serial_wave + 1u) % (kThreads / 64u);   // the searching wave whose doings are traced
+    laps = serial;
 
     // The blocks of a group of objects.  First one lane per object: the trees and the block's head (a Huffman
     // construction is a chain of dependent accesses that lanes cannot share but can each have one of), as many lanes at
@@ -460,7 +471,9 @@ __global__ __launch_bounds__(WaveClass<NMAX>::kThreads, WaveClass<NMAX>::kWavesP
                 uint32_t* const grab = &sh.grab[t & 1u];
                 zw::Walk k;
                 bool holds = false, dry = false, hurried = false;   // holds: k's answer is not stored yet; dry: the tile has no position left
-                uint64_t t_begin = __builtin_readcyclecounter(), t_dry = 0;
+                const uint64_t t_begin = tracing ? __builtin_readcyclecounter() : 0;
+                uint64_t t_dry = 0;
+                uint32_t rounds = 0, rounds_after = 0, entries_after = 0;
                 for (;;) {
                     const uint64_t done = __ballot(k.state == zw::Walk::kDone);
                     if (done == ~0ull || (!dry && __builtin_popcountll(done) >= int(kRefill))) {
@@ -480,25 +493,28 @@ __global__ __launch_bounds__(WaveClass<NMAX>::kThreads, WaveClass<NMAX>::kWavesP
                         if (__ballot(k.state != zw::Walk::kDone || holds) == 0) break;
                     }
                     if (!dry) {
-                        ++walking[2];
+                        ++rounds;
 #pragma unroll
                         for (uint32_t hop = 0; hop < kHopsInARow; ++hop)
                             if (k.state == zw::Walk::kHop) zw::walk_hop(k, d, chain);
                     } else {
                         // The tile is handed out and ends with its longest chain: what is still walking goes entry by entry
                         // in a loop of nothing else, ahead of the waves that have positions left to take.
-                        if (!hurried) { hurried = true; __builtin_amdgcn_s_setprio(2); t_dry = __builtin_readcyclecounter(); }
-                        ++walking[3];
+                        if (!hurried) { hurried = true; __builtin_amdgcn_s_setprio(2); t_dry = tracing ? __builtin_readcyclecounter() : 0; }
+                        ++rounds_after;
                         for (uint32_t hop = 0; hop < kHopsAtTheEnd && __ballot(k.state == zw::Walk::kHop) != 0; ++hop) {
-                            ++walking[5];
+                            ++entries_after;
                             if (k.state == zw::Walk::kHop) zw::walk_hop(k, d, chain);
                         }
                     }
                     if (k.state == zw::Walk::kCompare) zw::walk_compare(k, d);
                 }
                 if (hurried) __builtin_amdgcn_s_setprio(0);
-                const uint64_t t_end = __builtin_readcyclecounter();
-                if (t_dry) { walking[0] += t_dry - t_begin; walking[1] += t_end - t_dry; } else walking[0] += t_end - t_begin;
+                if (reports && tracing) {
+                    const uint64_t t_end = __builtin_readcyclecounter();
+                    count(8, (t_dry ? t_dry : t_end) - t_begin); count(9, t_dry ? t_end - t_dry : 0);
+                    count(10, rounds); count(11, rounds_after); count(13, entries_after);
+                }
             };
             if (!serial) {
                 if (tile < tiles) search_tile(tile);
@@ -564,10 +580,10 @@ __global__ __launch_bounds__(WaveClass<NMAX>::kThreads, WaveClass<NMAX>::kWavesP
                 lap(3);
                 if (tile < tiles) search_tile(tile);         // and then it searches with the others
             }
-            const uint64_t t_arrive = __builtin_readcyclecounter();
+            const uint64_t t_arrive = tracing ? __builtin_readcyclecounter() : 0;
             __syncthreads();
-            walking[4] += __builtin_readcyclecounter() - t_arrive;
-            if (serial) lap(2);                             // (what the serial wave waited for the searches)
+            if (reports && tracing) count(12, __builtin_readcyclecounter() - t_arrive);
+            lap(2);                                         // (what the serial wave waited for the searches)
         }
         // ---- the symbols into zlib's form (a literal's byte is read only now) and their counts, a symbol per thread
         const uint32_t n_sym = sh.n_sym;
@@ -601,13 +617,11 @@ __global__ __launch_bounds__(WaveClass<NMAX>::kThreads, WaveClass<NMAX>::kWavesP
         lap(4);
         if (++in_group == kGroup) { write_blocks(in_group); in_group = 0; }
         else __syncthreads();                               // the next object reuses every array
-        ++spent[7];
+        if (serial) count(7, 1);
     }
     if (in_group) write_blocks(in_group);
-    if (b.trace && serial && lane == 0)
-        for (int k = 0; k < 8; ++k) if (spent[k]) atomicAdd(reinterpret_cast<unsigned long long*>(&b.trace[k]), (unsigned long long)spent[k]);
-    if (b.trace && wave == (serial_wave + 1u) % (kThreads / 64u) && lane == 0)
-        for (int k = 0; k < 6; ++k) if (walking[k]) atomicAdd(reinterpret_cast<unsigned long long*>(&b.trace[8 + k]), (unsigned long long)walking[k]);
+    __syncthreads();
+    if (tracing && tid < 14 && sh.trace[tid]) atomicAdd(reinterpret_cast<unsigned long long*>(&b.trace[tid]), sh.trace[tid]);
 }
 
 uint64_t deflate_workspace_bytes(uint32_t lanes) { return (uint64_t)lanes * (zd::work_bytes() + zd::small_bytes()); }
