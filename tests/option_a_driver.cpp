@@ -1,6 +1,6 @@
 // A caller written against the REFERENCE's interface (the free functions of its src/commit.hpp:8-25),
 // linked against this repository's object_store.cpp instead of the reference's commit.cpp: the rehearsal
-// of the drop-in described in INTEGRATION.md, Option A.  Built by vit_amd/build.py to
+// of the source-level drop-in (the reference's callers unchanged, its commit.cpp replaced).  Built by vit_amd/build.py to
 // vit_amd/bin/option_a_driver; run by tests/test_option_a.py.
 //
 //   option_a_driver helpers                      the helpers that need no device (hex, paths)

@@ -1,4 +1,4 @@
-"""INTEGRATION.md Option A rehearsed: a program that calls the reference's free functions
+"""The source-level drop-in rehearsed: a program that calls the reference's free functions
 (src/commit.hpp:8-25) links against this repository's object_store.cpp instead of the reference's
 commit.cpp.  The helpers need no device; the writers are run on both sides of the store's small-work bound:
 on the store's own threads (no device, CPU test) and through the GPU hasher."""

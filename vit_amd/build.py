@@ -80,7 +80,7 @@ def build_cli(force=False, verbose=False):
 
 def build_driver(force=False, verbose=False):
     """tests/option_a_driver.cpp: a caller of the reference's free functions linked against object_store.cpp
-    (the drop-in of INTEGRATION.md, Option A), for tests/test_option_a.py."""
+    (the drop-in in which this file takes the place of the reference's commit.cpp), for tests/test_option_a.py."""
     srcs = [DRIVER_SOURCE, os.path.join(CSRC, "object_store.cpp")] + [os.path.join(CSRC, s) for s in HOST_SOURCES]
     if not os.path.exists(DRIVER_SOURCE):
         return None
