@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(DeflateBatch b, uint32_t on
 // that lanes cannot share but can each have one of.  A block that zlib stores is copied by all threads.  Device
 // memory sees the object once, its symbols out and in, the tree arrays, and its stream once: 10 (text-like) to 20
 // (incompressible) bytes over the fabric per input byte.  Four size classes (LDS per workgroup, workgroups per CU):
-// up to 1536 bytes (22 KiB, 4), 4608 (39 KiB, 4), 9216 (68 KiB, 2), 16382 (121 KiB, 1); every class is one launch
+// up to 1536 bytes (37 KiB, 4), 4608 (39 KiB, 4), 9216 (76 KiB, 2), 16382 (145 KiB, 1); every class is one launch
 // over the batch, each workgroup taking the objects of its class.
 // What bounds it (text-like 4 KiB objects, 1.5 M/s): a tile is done when its longest chain is, entry by entry at
 // some 900 clocks an entry in a wave that shares its SIMD with three others; the VALUs are busy 40 % of the time.
@@ -152,6 +152,7 @@ template <int NMAX, int BKBITS> struct WaveShared {
         struct { uint16_t d_buf[NMAX + 2]; uint8_t l_buf[NMAX + 2]; } sym;   // then the block's symbols
     } a;
     uint16_t entry[NMAX + 64];                              // the chains (zw::Chain)
+    uint32_t spare[(NMAX <= 1536 ? 15616 : 4) / 4];         // (the smallest class has LDS to spare: room for the Huffman heaps of all 32 lanes that build trees)
     zw::Found found[2][kScanTile];                          // the searches' answers for the positions of two tiles
     uint32_t grab[2];                                       // per tile: how many of its positions have been handed out
     uint16_t lt_fc[zd::kLCodes + 2], dt_fc[zd::kDCodes + 2];   // the symbols' counts
